@@ -1,0 +1,201 @@
+"""Generate tests/golden/*.npz from the reference's own classes (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Run:  python -m oracle.make_golden
+Requires /root/reference (imported through oracle/reference_loader.py stubs).
+Every fixture holds inputs, seeds and the *reference's* outputs on small
+configurations with every parameter re-randomised; weights are
+regenerated from their seed by the oracle's `random_*` helpers and guarded by a
+stored checksum.  The reference never travels to the GPU box; these vectors do.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import dit as odit
+from . import oobleck as ovae
+from . import reference_loader as rl
+from . import sampler as osmp
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def checksum(sd: dict) -> np.ndarray:
+    tot = sum(float(v.double().sum()) for v in sd.values())
+    atot = sum(float(v.double().abs().sum()) for v in sd.values())
+    return np.array([tot, atot])
+
+
+def save(name: str, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def toy_score(x, t, y):
+    """Closed-form stand-in score used by the sampler-only fixtures."""
+    tt = t.reshape(-1, 1, 1, 1)
+    return -(x - y) * 0.05 / (1 + tt) + 0.01 * torch.tanh(x)
+
+
+def gen_sde_tables(ns):
+    out = {}
+    for N in (10, 30):
+        ref = ns.OUVESDE(theta=1.5, sigma_min=0.96, sigma_max=10.0, N=N)
+        ts = torch.linspace(ref.T, 0.03, N)
+        std = ref._std(ts)
+        _, g = ref.sde(torch.zeros(N), ts, torch.zeros(N))
+        _, G = ref.discretize(torch.zeros(N), ts, torch.zeros(N))
+        out[f"t_{N}"] = ts
+        out[f"std_{N}"] = std
+        out[f"g_{N}"] = g
+        out[f"G_{N}"] = G
+        out[f"stdT_{N}"] = ref._std(torch.ones(1))
+    save("sde_tables", **out)
+
+
+def gen_sampler_toy(ns):
+    B, n, D, T, N = 2, 2, 64, 8, 10
+    g = torch.Generator().manual_seed(100)
+    y = torch.randn((B, 1, D, T), generator=g)
+    out = {"y": y, "N": N, "eps": 0.03, "snr": 0.5, "seed": 5}
+    ref_sde = ns.OUVESDE(theta=1.5, sigma_min=0.96, sigma_max=10.0, N=N)
+    for c in (0, 1, 2):
+        for dn in (True, False):
+            torch.manual_seed(5)
+            smp = ns.sdes.get_pc_sampler("reverse_diffusion", "ald", sde=ref_sde, score_fn=toy_score,
+                                         y=y, eps=0.03, snr=0.5, corrector_steps=c, denoise=dn,
+                                         n_spkrs=n)
+            x, nfe = smp()
+            out[f"x_c{c}_dn{int(dn)}"] = x
+            out[f"nfe_c{c}_dn{int(dn)}"] = nfe
+    # 3-speaker variant (n_spkrs must be passed explicitly)
+    torch.manual_seed(6)
+    smp = ns.sdes.get_pc_sampler("reverse_diffusion", "ald", sde=ref_sde, score_fn=toy_score, y=y,
+                                 eps=0.03, snr=0.5, corrector_steps=1, denoise=True, n_spkrs=3)
+    out["x_3spk"], _ = smp()
+    save("sampler_toy", **out)
+
+
+def gen_dit(ns):
+    for tag, n_src, T in (("2spk", 2, 8), ("3spk", 3, 5)):
+        cfg = odit.DiTConfig(n_src=n_src, embed_dim=128, depth=2, num_heads=2)
+        sd = odit.random_dit_weights(cfg, 11)
+        ref = ns.DiffusionTransformer(**cfg.reference_kwargs()).eval()
+        ref.load_state_dict(sd, strict=False)
+        g = torch.Generator().manual_seed(12)
+        B = 2
+        xt = 3.0 * torch.randn((B, n_src, 64, T), generator=g)
+        mix = torch.randn((B, 1, 64, T), generator=g)
+        t = torch.tensor([0.9, 0.13])
+        with torch.no_grad():
+            out = ref(xt.flatten(1, 2), t, input_concat_cond=mix.squeeze(1)).unflatten(1, (n_src, 64))
+        save(f"dit_tiny_{tag}", xt=xt, mix=mix, t=t, out=out, wsum=checksum(sd), seed=11,
+             embed_dim=128, depth=2, num_heads=2, n_src=n_src)
+
+
+def _ref_vae(ns, cfg):
+    dec = ns.OobleckDecoder(out_channels=1, channels=cfg.channels, latent_dim=cfg.latent_dim,
+                            c_mults=list(cfg.c_mults), strides=list(cfg.strides),
+                            use_snake=cfg.use_snake).eval()
+    enc = ns.OobleckEncoder(in_channels=1, channels=cfg.channels, latent_dim=cfg.enc_latent_dim,
+                            c_mults=list(cfg.c_mults), strides=list(cfg.strides),
+                            use_snake=cfg.use_snake).eval()
+    return enc, dec
+
+
+def tiny_vae_weights(cfg, seed):
+    sd = {}
+    sd.update(ovae.random_weights(ovae.encoder_param_shapes(cfg, "encoder."), seed))
+    sd.update(ovae.random_weights(ovae.decoder_param_shapes(cfg, "decoder."), seed + 1))
+    return sd
+
+
+def _sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def gen_vae(ns):
+    for snake in (False, True):
+        cfg = ovae.OobleckConfig(channels=8, use_snake=snake)
+        sd = tiny_vae_weights(cfg, 21)
+        enc, dec = _ref_vae(ns, cfg)
+        enc.load_state_dict(_sub(sd, "encoder."))
+        dec.load_state_dict(_sub(sd, "decoder."))
+        g = torch.Generator().manual_seed(22)
+        z = torch.randn((3, 64, 2), generator=g)
+        wav_in = 0.3 * torch.randn((2, 1, 4096), generator=g)
+        vn = torch.randn((2, 64, 2), generator=g)
+        with torch.no_grad():
+            wav = dec(z)
+            e = enc(wav_in)
+            torch.manual_seed(23)
+            lat = ns.vae_sample(*e.chunk(2, dim=1))[0]
+        torch.manual_seed(23)
+        vn = torch.randn((2, 64, 2))
+        save(f"vae_tiny_{'snake' if snake else 'elu'}", z=z, wav=wav, wav_in=wav_in, enc_out=e,
+             vae_noise=vn, latent=lat, wsum=checksum(sd), seed=21, channels=8)
+
+
+def gen_e2e(ns):
+    """encode -> PC sampler (DiT score) -> decode, composed from the reference's
+    own pieces exactly as LatentDiffSep.separate does (diffsep_latent.py:471-487)."""
+    vcfg = ovae.OobleckConfig(channels=8)
+    vsd = tiny_vae_weights(vcfg, 31)
+    enc, dec = _ref_vae(ns, vcfg)
+    enc.load_state_dict(_sub(vsd, "encoder."))
+    dec.load_state_dict(_sub(vsd, "decoder."))
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    ref_dit = ns.DiffusionTransformer(**dcfg.reference_kwargs()).eval()
+    ref_dit.load_state_dict(dsd, strict=False)
+
+    def score(xt, t, mix):
+        return ref_dit(xt.flatten(1, 2), t, input_concat_cond=mix.squeeze(1)).unflatten(1, (2, 64))
+
+    B, L, N = 2, 4000, 4
+    g = torch.Generator().manual_seed(33)
+    mix = 0.3 * torch.randn((B, 1, L), generator=g)
+    sde = ns.OUVESDE(theta=1.5, sigma_min=0.96, sigma_max=10.0, N=N)
+    torch.manual_seed(34)
+    with torch.no_grad():
+        xin = ns.torch_utils.pad(mix, vcfg.hop)
+        e = enc(xin)
+        lat, _ = ns.vae_sample(*e.chunk(2, dim=1))
+        y = lat.unsqueeze(1)
+        smp = ns.sdes.get_pc_sampler("reverse_diffusion", "ald", sde=sde, score_fn=score, y=y,
+                                     eps=0.03, snr=0.5, corrector_steps=1, denoise=True, n_spkrs=2)
+        x, nfe = smp()
+        wav = dec(x.reshape(B * 2, 64, -1)).reshape(B, 2, -1)[..., :L]
+    save("e2e_tiny", mix=mix, y=y, x=x, wav=wav, nfe=nfe, seed=34, N=N,
+         wsum_vae=checksum(vsd), wsum_dit=checksum(dsd))
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(4)
+    ns = rl.load()
+    print("generating golden vectors from", rl.REF_ROOT)
+    gen_sde_tables(ns)
+    gen_sampler_toy(ns)
+    gen_dit(ns)
+    gen_vae(ns)
+    gen_e2e(ns)
+    try:
+        from . import make_golden_ncsnpp
+        make_golden_ncsnpp.main(save, checksum)
+    except ImportError:
+        pass
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""Oracle (CPU restatement) vs the committed golden vectors that
+oracle/make_golden.py captured from the reference's own classes.
+Tolerances: fp32 round-off only (max-abs <= 2e-5 relative to O(1)-O(10) data)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit as odit
+from oracle import oobleck as ovae
+from oracle import pipeline, sampler
+from oracle.make_golden import checksum, tiny_vae_weights, toy_score, _sub
+
+T = torch.from_numpy
+
+
+def close(a, b, tol=2e-5):
+    a = a if isinstance(a, torch.Tensor) else T(np.asarray(a))
+    b = b if isinstance(b, torch.Tensor) else T(np.asarray(b))
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max-abs {err} > {tol}*{scale}"
+
+
+def test_sde_tables(golden):
+    g = golden("sde_tables")
+    for N in (10, 30):
+        sde = sampler.OUVE(N=N)
+        ts = torch.linspace(1, 0.03, N)
+        close(ts, g[f"t_{N}"], 1e-7)
+        close(sde.std(ts), g[f"std_{N}"], 1e-6)
+        close(sde.diffusion(ts), g[f"g_{N}"], 1e-6)
+        co = sampler.step_coefficients(sde, ts, 0.5)
+        close(co["G"], g[f"G_{N}"], 1e-6)
+        close(sde.std(torch.ones(1)), g[f"stdT_{N}"], 1e-6)
+
+
+@pytest.mark.parametrize("c", [0, 1, 2])
+@pytest.mark.parametrize("dn", [True, False])
+def test_sampler_toy_bit_exact(golden, c, dn):
+    g = golden("sampler_toy")
+    y = T(g["y"])
+    N = int(g["N"])
+    noise = sampler.draw_noise(int(g["seed"]), 1 + N * (c + 1), (2, 2, 64, 8))
+    x, nfe = sampler.pc_sample(toy_score, y, noise, sampler.OUVE(N=N), eps=0.03, snr=0.5,
+                               corrector_steps=c, denoise=dn, n_spkrs=2)
+    assert nfe == int(g[f"nfe_c{c}_dn{int(dn)}"]) == N * (c + 1)
+    assert torch.equal(x, T(g[f"x_c{c}_dn{int(dn)}"]))
+
+
+def test_sampler_three_speakers(golden):
+    g = golden("sampler_toy")
+    y = T(g["y"])
+    noise = sampler.draw_noise(6, 1 + 10 * 2, (2, 3, 64, 8))
+    x, _ = sampler.pc_sample(toy_score, y, noise, sampler.OUVE(N=10), eps=0.03, snr=0.5,
+                             corrector_steps=1, denoise=True, n_spkrs=3)
+    assert torch.equal(x, T(g["x_3spk"]))
+
+
+@pytest.mark.parametrize("tag", ["2spk", "3spk"])
+def test_dit_tiny(golden, tag):
+    g = golden(f"dit_tiny_{tag}")
+    cfg = odit.DiTConfig(n_src=int(g["n_src"]), embed_dim=int(g["embed_dim"]),
+                         depth=int(g["depth"]), num_heads=int(g["num_heads"]))
+    sd = odit.random_dit_weights(cfg, int(g["seed"]))
+    np.testing.assert_allclose(checksum(sd), g["wsum"], rtol=1e-9)
+    out = odit.DiTScore(sd, cfg)(T(g["xt"]), T(g["t"]), T(g["mix"]))
+    close(out, g["out"])
+
+
+@pytest.mark.parametrize("act", ["elu", "snake"])
+def test_vae_tiny(golden, act):
+    g = golden(f"vae_tiny_{act}")
+    cfg = ovae.OobleckConfig(channels=int(g["channels"]), use_snake=(act == "snake"))
+    sd = tiny_vae_weights(cfg, int(g["seed"]))
+    np.testing.assert_allclose(checksum(sd), g["wsum"], rtol=1e-9)
+    close(ovae.decoder_forward(sd, cfg, T(g["z"]), "decoder."), g["wav"])
+    e = ovae.encoder_forward(sd, cfg, T(g["wav_in"]), "encoder.")
+    close(e, g["enc_out"])
+    close(ovae.vae_sample(e, T(g["vae_noise"])), g["latent"])
+
+
+def test_pad_full_extra_hop():
+    x = torch.randn(1, 1, 4096)
+    assert sampler.pad_to_hop(x, 2048).shape[-1] == 6144      # reference quirk F7
+    assert sampler.pad_to_hop(x[..., :4000], 2048).shape[-1] == 4096
+    assert sampler.pad_to_hop(x[..., :0], 2048).shape[-1] == 2048
+
+
+def test_weight_norm_fold_transposed_axis():
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn((6, 4, 8), generator=g)
+    gg = torch.rand((6, 1, 1), generator=g) + 0.5
+    w = ovae.fold_weight_norm({"c.weight_g": gg, "c.weight_v": v}, "c.")
+    torch.testing.assert_close(w.flatten(1).norm(dim=1), gg.flatten())
+
+
+def test_e2e_tiny(golden):
+    g = golden("e2e_tiny")
+    vcfg = ovae.OobleckConfig(channels=8)
+    vsd = tiny_vae_weights(vcfg, 31)
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    np.testing.assert_allclose(checksum(vsd), g["wsum_vae"], rtol=1e-9)
+    np.testing.assert_allclose(checksum(dsd), g["wsum_dit"], rtol=1e-9)
+    mix = T(g["mix"])
+    r = pipeline.separate(odit.DiTScore(dsd, dcfg), vsd, vcfg, mix, sampler.OUVE(N=int(g["N"])),
+                          int(g["seed"]), n_spkrs=2, eps=0.03, snr=0.5, corrector_steps=1,
+                          target_dim=mix.shape[-1])
+    assert r["nfe"] == int(g["nfe"])
+    close(r["y"], g["y"])
+    close(r["x"], g["x"], 5e-5)
+    close(r["wav"], g["wav"], 5e-5)
