@@ -1,0 +1,51 @@
+// Shared device/host helpers for the gfx950 (MI355X) separation engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DSN_WAVE 64
+
+// ---- precision policy -----------------------------------------------------
+// An activation / weight operand of an MFMA contraction is stored as P bf16
+// "planes": plane 0 = bf16(v) (hi), plane 1 = bf16(v - hi) (lo).  P == 1 is the
+// plain bf16 mode; P == 2 ("bf16x3") evaluates hi*hi + hi*lo + lo*hi on the
+// bf16 matrix cores with fp32 accumulation: ~2^-16 relative operand error at
+// 1/3 of the bf16 MFMA rate (gfx950 has no xf32, and f32-input MFMA runs at
+// 1/16 of the bf16 rate).
+// (DSN_PREC_BF16 = 1 plane, DSN_PREC_BF16X3 = 2 planes: include/ditsep_hip.h)
+
+// activations applied by producer epilogues when writing operand planes
+enum { DSN_ACT_NONE = 0, DSN_ACT_ELU = 1, DSN_ACT_SNAKE = 2, DSN_ACT_SILU = 3 };
+// transform of the fp32 output
+enum { DSN_F32_NONE = 0, DSN_F32_TANH = 1 };
+
+__device__ __forceinline__ float dsn_elu(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float dsn_silu(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float dsn_snake(float v, float alpha, float inv_beta) {
+  float s = __sinf(v * alpha);
+  return v + inv_beta * s * s;
+}
+
+__device__ __forceinline__ void dsn_split(float v, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)v;
+  lo = (bf16_t)(v - (float)hi);
+}
+
+// wave-wide reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

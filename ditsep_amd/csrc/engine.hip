@@ -1,0 +1,1012 @@
+// Engine + C-ABI (include/ditsep_hip.h) of the MI355X separation path.
+//
+// Host side of the native library: owns the packed weights and the activation
+// workspace in HBM, and turns one call of the reference's entry points into a
+// fixed sequence of gfx950 kernel launches on the caller's HIP stream
+// (optionally captured into a hipGraph and replayed).  Nothing here touches
+// torch; the Python facade passes raw device pointers.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ditsep_hip.h"
+#include "igemm.h"
+#include "kernels.h"
+
+namespace {
+
+struct Err : std::runtime_error {
+  int code;
+  Err(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] void fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Err(code, buf);
+}
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) fail(DSN_EHIP, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                        \
+  } while (0)
+
+struct DevTensor {
+  float* p = nullptr;
+  std::vector<long> shape;
+  long numel = 0;
+};
+
+struct Packed {  // K-major packed operand planes of one contraction
+  bf16_t* w = nullptr;
+  long ps = 0;
+  int N = 0, K = 0, Cin = 0, taps = 0;
+  float* bias = nullptr;
+  int bias_mod = 1;
+};
+
+struct ActP {  // producer-side activation
+  int kind = DSN_ACT_NONE;
+  float* a = nullptr;
+  float* ib = nullptr;
+  int mod = 1;
+};
+
+struct DitLayer {
+  float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+  Packed qkv, out, ff1, ff2;
+};
+
+struct ResUnit {
+  ActP act0, act2;  // act0 is applied by the PRODUCER of the unit's input
+  Packed conv7, conv1;
+  int dil = 1;
+};
+
+struct VaeBlock {
+  ActP act;     // block-level activation (before convT / before strided conv)
+  Packed conv;  // ConvTranspose1d (decoder) or strided Conv1d (encoder)
+  ResUnit ru[3];
+  int cin = 0, cout = 0, stride = 1;
+};
+
+struct Graph {
+  hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
+
+struct dsn_ctx {
+  dsn_config cfg;
+  std::string err;
+  int P = 2;
+  bool finalized = false;
+  bool use_graphs = false;
+  std::map<std::string, DevTensor> raw;
+  std::vector<void*> allocs;
+  std::map<std::string, std::pair<void*, size_t>> ws;
+  uint64_t ws_epoch = 0;  // bumped on every workspace (re)allocation -> graphs invalid
+
+  // DiT
+  float* tf_w = nullptr;
+  Packed t1, t2, pre, pin, pout, post;
+  std::vector<DitLayer> layers;
+  // VAE
+  Packed dec_in;
+  std::vector<VaeBlock> dec_blocks;
+  ActP dec_final_act;
+  float* dec_out_w = nullptr;  // [7][C0]
+  int dec_out_taps = 7;
+  float *enc_in_w = nullptr, *enc_in_b = nullptr;
+  std::vector<VaeBlock> enc_blocks;
+  ActP enc_final_act;
+  Packed enc_out;
+
+  std::map<std::string, Graph> graphs;
+
+  // ---------------------------------------------------------------- memory
+  void* dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) fail(DSN_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    allocs.push_back(p);
+    return p;
+  }
+  template <class T>
+  T* wsbuf(const std::string& name, size_t count) {
+    const size_t bytes = count * sizeof(T) + 256;
+    auto it = ws.find(name);
+    if (it != ws.end() && it->second.second >= bytes) return (T*)it->second.first;
+    if (it != ws.end()) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipFree(it->second.first));
+      ws.erase(it);
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) fail(DSN_ENOMEM, "workspace %s: hipMalloc(%zu) failed", name.c_str(), bytes);
+    ws[name] = {p, bytes};
+    ++ws_epoch;
+    return (T*)p;
+  }
+  int64_t ws_bytes() const {
+    int64_t t = 0;
+    for (auto& kv : ws) t += (int64_t)kv.second.second;
+    return t;
+  }
+
+  // ---------------------------------------------------------------- weights
+  const DevTensor& get(const std::string& name) const {
+    auto it = raw.find(name);
+    if (it == raw.end()) fail(DSN_ESTATE, "missing weight '%s'", name.c_str());
+    return it->second;
+  }
+  bool has(const std::string& name) const { return raw.count(name) != 0; }
+  float* maybe(const std::string& name) const { return has(name) ? raw.at(name).p : nullptr; }
+
+  Packed pack_linear(const std::string& wname, const std::string& bname, bool swiglu, hipStream_t st) {
+    const DevTensor& w = get(wname);
+    if (w.shape.size() < 2) fail(DSN_EINVAL, "%s: expected a matrix", wname.c_str());
+    Packed p;
+    p.N = (int)w.shape[0];
+    p.K = (int)(w.numel / w.shape[0]);
+    p.Cin = p.K;
+    p.taps = 1;
+    p.ps = (long)p.N * p.K;
+    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
+    launch_pack_weight(w.p, nullptr, p.w, p.ps, P, swiglu ? PACK_LINEAR_SWIGLU : PACK_LINEAR, p.N, p.K, p.K, p.N,
+                       1, 1, st);
+    if (!bname.empty() && has(bname)) {
+      const DevTensor& b = get(bname);
+      if (b.numel != p.N) fail(DSN_EINVAL, "%s: bias size mismatch", bname.c_str());
+      if (swiglu) {
+        p.bias = (float*)dmalloc(sizeof(float) * p.N);
+        launch_pack_bias_swiglu(b.p, p.bias, p.N, st);
+      } else {
+        p.bias = b.p;
+      }
+      p.bias_mod = p.N;
+    }
+    return p;
+  }
+
+  // weight-normed Conv1d [Cout][Cin][kw] (or plain `weight`) -> [Cout][kw*Cin]
+  Packed pack_conv(const std::string& prefix, hipStream_t st) {
+    const bool wn = has(prefix + "weight_v");
+    const DevTensor& v = get(prefix + (wn ? "weight_v" : "weight"));
+    if (v.shape.size() != 3) fail(DSN_EINVAL, "%s: expected [Cout,Cin,k]", prefix.c_str());
+    const int Cout = (int)v.shape[0], Cin = (int)v.shape[1], kw = (int)v.shape[2];
+    float* scale = nullptr;
+    if (wn) {
+      scale = (float*)dmalloc(sizeof(float) * Cout);
+      launch_wn_scale(v.p, get(prefix + "weight_g").p, scale, Cout, (long)Cin * kw, st);
+    }
+    Packed p;
+    p.N = Cout;
+    p.Cin = Cin;
+    p.taps = kw;
+    p.K = Cin * kw;
+    p.ps = (long)p.N * p.K;
+    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
+    launch_pack_weight(v.p, scale, p.w, p.ps, P, PACK_CONV, p.N, p.K, Cin, Cout, kw, 1, st);
+    p.bias = maybe(prefix + "bias");
+    p.bias_mod = Cout;
+    return p;
+  }
+
+  // weight-normed ConvTranspose1d [Cin][Cout][2s] -> phase GEMM [s*Cout][2*Cin]
+  Packed pack_convT(const std::string& prefix, int stride, hipStream_t st) {
+    const bool wn = has(prefix + "weight_v");
+    const DevTensor& v = get(prefix + (wn ? "weight_v" : "weight"));
+    if (v.shape.size() != 3) fail(DSN_EINVAL, "%s: expected [Cin,Cout,k]", prefix.c_str());
+    const int Cin = (int)v.shape[0], Cout = (int)v.shape[1], kw = (int)v.shape[2];
+    if (kw != 2 * stride) fail(DSN_EINVAL, "%s: kernel %d != 2*stride %d", prefix.c_str(), kw, stride);
+    float* scale = nullptr;
+    if (wn) {
+      scale = (float*)dmalloc(sizeof(float) * Cin);
+      launch_wn_scale(v.p, get(prefix + "weight_g").p, scale, Cin, (long)Cout * kw, st);
+    }
+    Packed p;
+    p.N = stride * Cout;
+    p.Cin = Cin;
+    p.taps = 2;
+    p.K = 2 * Cin;
+    p.ps = (long)p.N * p.K;
+    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
+    launch_pack_weight(v.p, scale, p.w, p.ps, P, PACK_CONVT, p.N, p.K, Cin, Cout, kw, stride, st);
+    p.bias = maybe(prefix + "bias");
+    p.bias_mod = Cout;
+    return p;
+  }
+
+  ActP make_act(const std::string& prefix, int channels, hipStream_t st) {
+    ActP a;
+    a.mod = channels;
+    if (!cfg.vae_use_snake) {
+      a.kind = DSN_ACT_ELU;
+      return a;
+    }
+    a.kind = DSN_ACT_SNAKE;
+    a.a = (float*)dmalloc(sizeof(float) * channels);
+    a.ib = (float*)dmalloc(sizeof(float) * channels);
+    launch_snake_params(get(prefix + "alpha").p, get(prefix + "beta").p, a.a, a.ib, channels, st);
+    return a;
+  }
+
+  ResUnit make_ru(const std::string& prefix, int ch, int dil, hipStream_t st) {
+    ResUnit r;
+    r.dil = dil;
+    r.act0 = make_act(prefix + "layers.0.", ch, st);
+    r.conv7 = pack_conv(prefix + "layers.1.", st);
+    r.act2 = make_act(prefix + "layers.2.", ch, st);
+    r.conv1 = pack_conv(prefix + "layers.3.", st);
+    return r;
+  }
+
+  void finalize(hipStream_t st) {
+    const int D = cfg.dit_embed_dim;
+    if (cfg.score_kind == DSN_SCORE_DIT) {
+      const std::string sp = "score_model.";
+      if (D % 64 != 0 || cfg.dit_heads <= 0 || D / cfg.dit_heads != 64 || D % cfg.dit_heads != 0)
+        fail(DSN_EINVAL, "DiT: embed_dim must be heads x 64 (got %d / %d heads)", D, cfg.dit_heads);
+      tf_w = get(sp + "timestep_features.weight").p;
+      t1 = pack_linear(sp + "to_timestep_embed.0.weight", sp + "to_timestep_embed.0.bias", false, st);
+      t2 = pack_linear(sp + "to_timestep_embed.2.weight", sp + "to_timestep_embed.2.bias", false, st);
+      pre = pack_linear(sp + "preprocess_conv.weight", "", false, st);
+      post = pack_linear(sp + "postprocess_conv.weight", "", false, st);
+      pin = pack_linear(sp + "transformer.project_in.weight", "", false, st);
+      pout = pack_linear(sp + "transformer.project_out.weight", "", false, st);
+      layers.resize(cfg.dit_depth);
+      for (int i = 0; i < cfg.dit_depth; ++i) {
+        const std::string lp = sp + "transformer.layers." + std::to_string(i) + ".";
+        DitLayer& L = layers[i];
+        L.g1 = get(lp + "pre_norm.gamma").p;
+        L.be1 = maybe(lp + "pre_norm.beta");
+        L.g2 = get(lp + "ff_norm.gamma").p;
+        L.be2 = maybe(lp + "ff_norm.beta");
+        L.qkv = pack_linear(lp + "self_attn.to_qkv.weight", "", false, st);
+        L.out = pack_linear(lp + "self_attn.to_out.weight", "", false, st);
+        L.ff1 = pack_linear(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
+        L.ff2 = pack_linear(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
+      }
+    }
+    const int nb = cfg.vae_n_blocks;
+    const int ch = cfg.vae_channels;
+    std::vector<int> mult(nb + 1, 1);
+    for (int i = 0; i < nb; ++i) mult[i + 1] = cfg.vae_c_mults[i];
+    if (cfg.vae_has_decoder) {
+      const std::string dp = "vae.decoder.";
+      dec_in = pack_conv(dp + "layers.0.", st);
+      dec_blocks.resize(nb);
+      int li = 1;
+      for (int i = nb; i >= 1; --i, ++li) {
+        VaeBlock& b = dec_blocks[li - 1];
+        const std::string bp = dp + "layers." + std::to_string(li) + ".";
+        b.cin = mult[i] * ch;
+        b.cout = mult[i - 1] * ch;
+        b.stride = cfg.vae_strides[i - 1];
+        b.act = make_act(bp + "layers.0.", b.cin, st);
+        b.conv = pack_convT(bp + "layers.1.", b.stride, st);
+        const int dils[3] = {1, 3, 9};
+        for (int j = 0; j < 3; ++j)
+          b.ru[j] = make_ru(bp + "layers." + std::to_string(2 + j) + ".", b.cout, dils[j], st);
+      }
+      dec_final_act = make_act(dp + "layers." + std::to_string(li) + ".", mult[0] * ch, st);
+      // final conv (Cout = 1 per io channel; io_channels == 1 on this path): fold weight norm -> [k][C]
+      {
+        const std::string fp = dp + "layers." + std::to_string(li + 1) + ".";
+        const bool wn = has(fp + "weight_v");
+        const DevTensor& v = get(fp + (wn ? "weight_v" : "weight"));
+        if (v.shape[0] != 1) fail(DSN_EINVAL, "decoder io_channels must be 1 (got %ld)", v.shape[0]);
+        const int C = (int)v.shape[1], kw = (int)v.shape[2];
+        dec_out_taps = kw;
+        std::vector<float> hv(v.numel), hg(1, 1.f);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(hv.data(), v.p, sizeof(float) * v.numel, hipMemcpyDeviceToHost));
+        double nrm = 1.0, g = 1.0;
+        if (wn) {
+          HIPCHK(hipMemcpy(hg.data(), get(fp + "weight_g").p, sizeof(float), hipMemcpyDeviceToHost));
+          double ss = 0;
+          for (float x : hv) ss += (double)x * x;
+          nrm = sqrt(ss);
+          g = hg[0];
+        }
+        std::vector<float> w(kw * C);
+        for (int c = 0; c < C; ++c)
+          for (int k = 0; k < kw; ++k) w[k * C + c] = (float)(hv[c * kw + k] * ((float)g / (float)nrm));
+        dec_out_w = (float*)dmalloc(sizeof(float) * w.size());
+        HIPCHK(hipMemcpy(dec_out_w, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+      }
+    }
+    if (cfg.vae_has_encoder) {
+      const std::string ep = "vae.encoder.";
+      {
+        // first conv: Cin = 1, fold weight norm on the host (tiny) -> [Cout][k]
+        const std::string fp = ep + "layers.0.";
+        const bool wn = has(fp + "weight_v");
+        const DevTensor& v = get(fp + (wn ? "weight_v" : "weight"));
+        if (v.shape[1] != 1) fail(DSN_EINVAL, "encoder in_channels must be 1");
+        const int Cout = (int)v.shape[0], kw = (int)v.shape[2];
+        std::vector<float> hv(v.numel), hg(Cout, 1.f);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(hv.data(), v.p, sizeof(float) * v.numel, hipMemcpyDeviceToHost));
+        if (wn) HIPCHK(hipMemcpy(hg.data(), get(fp + "weight_g").p, sizeof(float) * Cout, hipMemcpyDeviceToHost));
+        for (int co = 0; co < Cout; ++co) {
+          float s = 1.f;
+          if (wn) {
+            float ss = 0;
+            for (int k = 0; k < kw; ++k) ss += hv[co * kw + k] * hv[co * kw + k];
+            s = hg[co] / sqrtf(ss);
+          }
+          for (int k = 0; k < kw; ++k) hv[co * kw + k] *= s;
+        }
+        enc_in_w = (float*)dmalloc(sizeof(float) * hv.size());
+        HIPCHK(hipMemcpy(enc_in_w, hv.data(), sizeof(float) * hv.size(), hipMemcpyHostToDevice));
+        enc_in_b = maybe(fp + "bias");
+      }
+      enc_blocks.resize(nb);
+      int li = 1;
+      for (int i = 0; i < nb; ++i, ++li) {
+        VaeBlock& b = enc_blocks[i];
+        const std::string bp = ep + "layers." + std::to_string(li) + ".";
+        b.cin = mult[i] * ch;
+        b.cout = mult[i + 1] * ch;
+        b.stride = cfg.vae_strides[i];
+        const int dils[3] = {1, 3, 9};
+        for (int j = 0; j < 3; ++j) b.ru[j] = make_ru(bp + "layers." + std::to_string(j) + ".", b.cin, dils[j], st);
+        b.act = make_act(bp + "layers.3.", b.cin, st);
+        b.conv = pack_conv(bp + "layers.4.", st);
+      }
+      enc_final_act = make_act(ep + "layers." + std::to_string(li) + ".", mult[nb] * ch, st);
+      enc_out = pack_conv(ep + "layers." + std::to_string(li + 1) + ".", st);
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    finalized = true;
+  }
+
+  // ---------------------------------------------------------------- GEMM helper
+  // dense conv-like contraction over channels-last planes
+  GemmDesc base_desc(const bf16_t* A, long a_ps, const Packed& w, int Bn, int rows_per_b, int Lin) {
+    GemmDesc d;
+    memset(&d, 0, sizeof d);
+    d.A = A;
+    d.a_ps = a_ps;
+    d.W = w.w;
+    d.w_ps = w.ps;
+    d.M = Bn * rows_per_b;
+    d.N = w.N;
+    d.Cin = w.Cin;
+    d.taps = w.taps;
+    d.rows_per_b = rows_per_b;
+    d.Lin = Lin;
+    d.in_stride = 1;
+    d.tap_dil = 1;
+    d.in_pad = 0;
+    d.in_bstride = (long)Lin * w.Cin;
+    d.out_bstride = (long)rows_per_b * w.N;
+    d.out_row_elems = w.N;
+    d.out_off = 0;
+    d.out_limit = d.out_bstride;
+    d.bias = w.bias;
+    d.bias_mod = w.bias_mod;
+    d.out_scale = 1.f;
+    d.act_mod = 1;
+    return d;
+  }
+  void set_act(GemmDesc& d, const ActP& a) {
+    d.act = a.kind;
+    d.act_a = a.a;
+    d.act_b = a.ib;
+    d.act_mod = a.mod;
+  }
+  void run(const GemmDesc& d, hipStream_t st) {
+    hipError_t e = igemm_launch(d, P, st);
+    if (e != hipSuccess) fail(DSN_EHIP, "igemm launch failed: %s (M=%d N=%d Cin=%d taps=%d)", hipGetErrorString(e),
+                              d.M, d.N, d.Cin, d.taps);
+  }
+
+  // ---------------------------------------------------------------- DiT score
+  // xt [B,n,Dl,T], t [B], mix [B,1,Dl,T] -> score token-major [B*T][n*Dl] in ws "sc"
+  float* dit_forward(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
+    const int n = cfg.n_src, Dl = cfg.latent_dim, D = cfg.dit_embed_dim, H = cfg.dit_heads;
+    const int io = n * Dl, din = io + Dl, S = T + 1;
+    const long Mt = (long)B * T, M = (long)B * S;
+    if (S > 256) fail(DSN_EINVAL, "DiT attention kernel supports at most 255 latent frames (got T=%d)", T);
+    float* U = wsbuf<float>("dit_U", Mt * din);
+    bf16_t* Up = wsbuf<bf16_t>("dit_Up", Mt * din * P);
+    bf16_t* H0 = wsbuf<bf16_t>("dit_H0", Mt * din * P);
+    float* X = wsbuf<float>("dit_X", M * D);
+    bf16_t* Ap = wsbuf<bf16_t>("dit_Ap", M * D * P);
+    float* QKV = wsbuf<float>("dit_QKV", M * 3 * D);
+    bf16_t* FF = wsbuf<bf16_t>("dit_FF", M * 4 * D * P);
+    bf16_t* TF = wsbuf<bf16_t>("dit_TF", (long)B * 256 * P);
+    bf16_t* TE = wsbuf<bf16_t>("dit_TE", (long)B * D * P);
+    float* O = wsbuf<float>("dit_O", Mt * io);
+    bf16_t* Op = wsbuf<bf16_t>("dit_Op", Mt * io * P);
+    float* SC = wsbuf<float>("sc", Mt * io);
+    const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
+    float* rc = wsbuf<float>("rope_cos", (long)257 * rot);
+    float* rs = wsbuf<float>("rope_sin", (long)257 * rot);
+    if (rope_S != S) {
+      launch_rope_tables(rc, rs, S, rot, st);
+      rope_S = S;
+    }
+
+    launch_pack_tokens(xt, io, mix, Dl, B, T, U, Up, Mt * din, P, st);
+    {  // h0 = U Wpre^T + U
+      GemmDesc d = base_desc(Up, Mt * din, pre, B, T, T);
+      d.resid = U;
+      d.out_planes = H0;
+      d.out_ps = Mt * din;
+      run(d, st);
+    }
+    {  // X[b, 1+t] = h0 Win^T
+      GemmDesc d = base_desc(H0, Mt * din, pin, B, T, T);
+      d.out_f32 = X;
+      d.out_bstride = (long)S * D;
+      d.out_off = D;
+      d.out_limit = (long)S * D;
+      run(d, st);
+    }
+    {  // timestep token -> X[b, 0]
+      launch_timestep_features(t, tf_w, B, 128, TF, (long)B * 256, P, st);
+      GemmDesc d = base_desc(TF, (long)B * 256, t1, B, 1, 1);
+      d.out_planes = TE;
+      d.out_ps = (long)B * D;
+      d.act = DSN_ACT_SILU;
+      run(d, st);
+      GemmDesc e = base_desc(TE, (long)B * D, t2, B, 1, 1);
+      e.out_f32 = X;
+      e.out_bstride = (long)S * D;
+      e.out_row_elems = 0;
+      e.out_limit = (long)S * D;
+      run(e, st);
+    }
+    for (int i = 0; i < cfg.dit_depth; ++i) {
+      const DitLayer& L = layers[i];
+      launch_layernorm_planes(X, L.g1, L.be1, Ap, M * D, P, (int)M, D, 1e-5f, st);
+      {
+        GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
+        d.out_f32 = QKV;
+        run(d, st);
+      }
+      launch_attention(QKV, rc, rs, rot, Ap, M * D, P, B, S, H, 64, st);
+      {
+        GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
+        d.resid = X;
+        d.out_f32 = X;
+        run(d, st);
+      }
+      launch_layernorm_planes(X, L.g2, L.be2, Ap, M * D, P, (int)M, D, 1e-5f, st);
+      {
+        GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
+        d.swiglu = 1;
+        d.out_planes = FF;
+        d.out_ps = M * 4 * D;
+        d.out_bstride = M * 4L * D;
+        d.out_row_elems = 4 * D;
+        d.out_limit = d.out_bstride;
+        run(d, st);
+      }
+      {
+        GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
+        d.resid = X;
+        d.out_f32 = X;
+        run(d, st);
+      }
+    }
+    launch_to_planes(X, Ap, M * D, P, M * D, st);
+    {  // o = X[b, 1+t] Wout^T
+      GemmDesc d = base_desc(Ap, M * D, pout, B, T, S);
+      d.in_pad = -1;
+      d.in_bstride = (long)S * D;
+      d.out_f32 = O;
+      d.out_planes = Op;
+      d.out_ps = Mt * io;
+      run(d, st);
+    }
+    {  // score = o Wpost^T + o
+      GemmDesc d = base_desc(Op, Mt * io, post, B, T, T);
+      d.resid = O;
+      d.out_f32 = SC;
+      run(d, st);
+    }
+    return SC;
+  }
+  int rope_S = -1;
+
+  float* score_tokens(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
+    if (!finalized) fail(DSN_ESTATE, "weights not finalized");
+    if (cfg.score_kind == DSN_SCORE_DIT) return dit_forward(xt, t, mix, B, T, st);
+    fail(DSN_ESTATE, "no score network configured (score_kind=%d)", cfg.score_kind);
+  }
+
+  // ---------------------------------------------------------------- OUVE scalars
+  struct Sched {
+    std::vector<float> t, std, step, gain, G;
+    float stdT;
+  };
+  float ouve_std(float t) const {
+    const double th = cfg.sde_theta, smin = cfg.sde_sigma_min, ls = log((double)cfg.sde_sigma_max / smin);
+    const float a = expf((float)(-2.0 * th) * t);
+    const float b = expf((float)(2.0 * (th + ls)) * t) - 1.f;
+    const float num = (float)(smin * smin) * a * b * (float)ls;
+    return sqrtf(num / (float)(th + ls));
+  }
+  Sched schedule(int N, float t_eps, float snr) const {
+    Sched s;
+    const double smin = cfg.sde_sigma_min, smax = cfg.sde_sigma_max, ls = log(smax / smin);
+    s.t.resize(N);
+    s.std.resize(N);
+    s.step.resize(N);
+    s.gain.resize(N);
+    s.G.resize(N);
+    // torch.linspace(1, eps, N) in fp32: step = (end-start)/(N-1); symmetric fill
+    const float start = 1.f, end = t_eps;
+    const float stp = N > 1 ? (end - start) / (float)(N - 1) : 0.f;
+    const int halfway = N / 2;
+    for (int i = 0; i < N; ++i) s.t[i] = i < halfway ? start + stp * (float)i : end - stp * (float)(N - 1 - i);
+    const float sqdt = sqrtf((float)(1.0 / N));
+    for (int i = 0; i < N; ++i) {
+      const float t = s.t[i];
+      s.std[i] = ouve_std(t);
+      const float q = snr * s.std[i];
+      s.step[i] = q * q * 2.f;
+      s.gain[i] = sqrtf(s.step[i] * 2.f);
+      const float sigma = (float)smin * powf((float)(smax / smin), t);
+      s.G[i] = sigma * (float)sqrt(2.0 * ls) * sqdt;
+    }
+    s.stdT = ouve_std(1.f);
+    return s;
+  }
+
+  // ---------------------------------------------------------------- sampler
+  // y [B,1,Dl,T]; noise [(1+N(c+1))][B,n,Dl,T]; returns device pointer of the result
+  float* pc_sample(const float* y, const float* noise, int B, int T, int N, int c, float snr, float t_eps,
+                   int denoise, hipStream_t st) {
+    const int n = cfg.n_src, Dl = cfg.latent_dim;
+    const long sz = (long)B * n * Dl * T;
+    float* x = wsbuf<float>("pc_x", sz);
+    float* xm = wsbuf<float>("pc_xm", sz);
+    float* tv = wsbuf<float>("pc_t", (long)B * N);
+    const Sched s = schedule(N, t_eps, snr);
+    {
+      std::vector<float> ht((size_t)B * N);
+      for (int i = 0; i < N; ++i)
+        for (int b = 0; b < B; ++b) ht[(size_t)i * B + b] = s.t[i];
+      HIPCHK(hipMemcpyAsync(tv, ht.data(), sizeof(float) * ht.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));  // ht is a stack-owned staging buffer
+    }
+    const float dt = (float)(1.0 / N);
+    const float* z = noise;
+    launch_pc_prior(y, z, x, s.stdT, B, n, Dl, T, st);
+    z += sz;
+    for (int i = 0; i < N; ++i) {
+      const float* ti = tv + (long)i * B;
+      for (int k = 0; k < c; ++k) {
+        float* sc = score_tokens(x, ti, y, B, T, st);
+        launch_pc_corrector(x, sc, z, s.step[i], s.gain[i], B, n, Dl, T, st);
+        z += sz;
+      }
+      float* sc = score_tokens(x, ti, y, B, T, st);
+      launch_pc_predictor(x, xm, y, sc, z, cfg.sde_theta, dt, s.G[i], B, n, Dl, T, st);
+      z += sz;
+    }
+    return denoise ? xm : x;
+  }
+
+  // ---------------------------------------------------------------- decoder
+  int hop() const {
+    int h = 1;
+    for (int i = 0; i < cfg.vae_n_blocks; ++i) h *= cfg.vae_strides[i];
+    return h;
+  }
+  // est [S][Dl][T] (S = B*n) -> wav fp32 [S][hop*T] in ws "dec_wav"
+  float* decode(const float* est, int S, int T, hipStream_t st) {
+    if (!cfg.vae_has_decoder) fail(DSN_ESTATE, "decoder not configured");
+    const int Dl = cfg.latent_dim;
+    long maxel = (long)S * T * dec_in.N;
+    {
+      long L = T;
+      for (auto& b : dec_blocks) {
+        L *= b.stride;
+        maxel = std::max(maxel, (long)S * L * b.cout);
+      }
+    }
+    bf16_t* zp = wsbuf<bf16_t>("dec_z", (long)S * T * Dl * P);
+    bf16_t* pa = wsbuf<bf16_t>("dec_pa", maxel * P);
+    bf16_t* pb = wsbuf<bf16_t>("dec_pb", maxel * P);
+    bf16_t* ph = wsbuf<bf16_t>("dec_ph", maxel * P);
+    float* xf = wsbuf<float>("dec_x", maxel);
+    launch_pack_tokens(est, Dl, nullptr, 0, S, T, nullptr, zp, (long)S * T * Dl, P, st);
+    long L = T;
+    {
+      GemmDesc d = base_desc(zp, (long)S * T * Dl, dec_in, S, T, T);
+      d.in_pad = (dec_in.taps - 1) / 2;
+      d.out_planes = pa;
+      d.out_ps = (long)S * T * dec_in.N;
+      set_act(d, dec_blocks[0].act);
+      run(d, st);
+    }
+    long a_ps = (long)S * T * dec_in.N;
+    for (size_t bi = 0; bi < dec_blocks.size(); ++bi) {
+      const VaeBlock& b = dec_blocks[bi];
+      const long Lo = L * b.stride;
+      const long o_ps = (long)S * Lo * b.cout;
+      {  // ConvTranspose1d as a 2-tap phase GEMM
+        GemmDesc d = base_desc(pa, a_ps, b.conv, S, (int)L + 1, (int)L);
+        d.tap_dil = -1;
+        d.out_bstride = Lo * b.cout;
+        d.out_row_elems = b.stride * b.cout;
+        d.out_off = -((b.stride + 1) / 2) * b.cout;
+        d.out_limit = Lo * b.cout;
+        d.out_f32 = xf;
+        d.out_planes = pb;
+        d.out_ps = o_ps;
+        set_act(d, b.ru[0].act0);
+        run(d, st);
+      }
+      for (int j = 0; j < 3; ++j) {
+        const ResUnit& r = b.ru[j];
+        {
+          GemmDesc d = base_desc(pb, o_ps, r.conv7, S, (int)Lo, (int)Lo);
+          d.tap_dil = r.dil;
+          d.in_pad = r.dil * (r.conv7.taps - 1) / 2;
+          d.out_planes = ph;
+          d.out_ps = o_ps;
+          set_act(d, r.act2);
+          run(d, st);
+        }
+        {
+          GemmDesc d = base_desc(ph, o_ps, r.conv1, S, (int)Lo, (int)Lo);
+          d.resid = xf;
+          d.out_planes = pb;
+          d.out_ps = o_ps;
+          if (j < 2) {
+            d.out_f32 = xf;
+            set_act(d, b.ru[j + 1].act0);
+          } else if (bi + 1 < dec_blocks.size()) {
+            set_act(d, dec_blocks[bi + 1].act);
+          } else {
+            set_act(d, dec_final_act);
+          }
+          run(d, st);
+        }
+      }
+      std::swap(pa, pb);
+      a_ps = o_ps;
+      L = Lo;
+    }
+    float* wav = wsbuf<float>("dec_wav", (long)S * L);
+    launch_conv_out1(pa, a_ps, P, dec_out_w, wav, S, (int)L, dec_blocks.back().cout, dec_out_taps,
+                     cfg.vae_final_tanh, st);
+    return wav;
+  }
+
+  // ---------------------------------------------------------------- encoder
+  // wav [S][L] (L multiple of hop) + noise [S][Dl][T] -> y [S][Dl][T]
+  void encode(const float* wav, const float* noise, float* y, int S, int L, hipStream_t st) {
+    if (!cfg.vae_has_encoder) fail(DSN_ESTATE, "encoder not configured");
+    const int Dl = cfg.latent_dim, c0 = cfg.vae_channels;
+    long maxel = (long)S * L * c0;
+    {
+      long l = L;
+      for (auto& b : enc_blocks) {
+        l /= b.stride;
+        maxel = std::max(maxel, (long)S * l * b.cout);
+      }
+    }
+    bf16_t* pa = wsbuf<bf16_t>("enc_pa", maxel * P);
+    bf16_t* ph = wsbuf<bf16_t>("enc_ph", maxel * P);
+    bf16_t* pb = wsbuf<bf16_t>("enc_pb", maxel * P);
+    float* xf = wsbuf<float>("enc_x", maxel);
+    long l = L;
+    long a_ps = (long)S * l * c0;
+    {
+      const ActP& a = enc_blocks[0].ru[0].act0;
+      launch_conv_in1(wav, enc_in_w, enc_in_b, S, L, c0, 7, xf, pa, a_ps, P, a.kind, a.a, a.ib, st);
+    }
+    for (size_t bi = 0; bi < enc_blocks.size(); ++bi) {
+      const VaeBlock& b = enc_blocks[bi];
+      for (int j = 0; j < 3; ++j) {
+        const ResUnit& r = b.ru[j];
+        {
+          GemmDesc d = base_desc(pa, a_ps, r.conv7, S, (int)l, (int)l);
+          d.tap_dil = r.dil;
+          d.in_pad = r.dil * (r.conv7.taps - 1) / 2;
+          d.out_planes = ph;
+          d.out_ps = a_ps;
+          set_act(d, r.act2);
+          run(d, st);
+        }
+        {
+          GemmDesc d = base_desc(ph, a_ps, r.conv1, S, (int)l, (int)l);
+          d.resid = xf;
+          d.out_planes = pa;
+          d.out_ps = a_ps;
+          if (j < 2) {
+            d.out_f32 = xf;
+            set_act(d, b.ru[j + 1].act0);
+          } else {
+            set_act(d, b.act);
+          }
+          run(d, st);
+        }
+      }
+      const long lo = l / b.stride;
+      const long o_ps = (long)S * lo * b.cout;
+      {  // strided conv k = 2s
+        GemmDesc d = base_desc(pa, a_ps, b.conv, S, (int)lo, (int)l);
+        d.in_stride = b.stride;
+        d.in_pad = (b.stride + 1) / 2;
+        d.out_planes = pb;
+        d.out_ps = o_ps;
+        if (bi + 1 < enc_blocks.size()) {
+          d.out_f32 = xf;
+          set_act(d, enc_blocks[bi + 1].ru[0].act0);
+        } else {
+          set_act(d, enc_final_act);
+        }
+        run(d, st);
+      }
+      std::swap(pa, pb);
+      a_ps = o_ps;
+      l = lo;
+    }
+    float* enc = wsbuf<float>("enc_out", (long)S * l * enc_out.N);
+    {
+      GemmDesc d = base_desc(pa, a_ps, enc_out, S, (int)l, (int)l);
+      d.in_pad = (enc_out.taps - 1) / 2;
+      d.out_f32 = enc;
+      run(d, st);
+    }
+    if (enc_out.N != 2 * Dl) fail(DSN_EINVAL, "encoder latent %d != 2*latent_dim %d", enc_out.N, 2 * Dl);
+    launch_vae_sample(enc, noise, y, S, Dl, (int)l, st);
+  }
+};
+
+// =========================================================================== C-ABI
+namespace {
+thread_local std::string g_create_err;
+
+template <class F>
+int guarded(dsn_ctx* ctx, F&& f) {
+  if (!ctx) return DSN_EINVAL;
+  try {
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    f();
+    return DSN_OK;
+  } catch (const Err& e) {
+    ctx->err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    ctx->err = e.what();
+    return DSN_EINVAL;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+dsn_ctx* dsn_create(const dsn_config* cfg) {
+  try {
+    if (!cfg) fail(DSN_EINVAL, "null config");
+    if (cfg->precision != DSN_PREC_BF16 && cfg->precision != DSN_PREC_BF16X3)
+      fail(DSN_EINVAL, "precision must be DSN_PREC_BF16 or DSN_PREC_BF16X3");
+    if (cfg->vae_n_blocks < 0 || cfg->vae_n_blocks > DSN_MAX_VAE_BLOCKS) fail(DSN_EINVAL, "bad vae_n_blocks");
+    if (cfg->n_src < 1 || cfg->latent_dim % 32 != 0) fail(DSN_EINVAL, "bad n_src / latent_dim");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) fail(DSN_EINVAL, "device %d out of range (%d GPUs)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    dsn_ctx* c = new dsn_ctx();
+    c->cfg = *cfg;
+    c->P = cfg->precision;
+    return c;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return nullptr;
+  }
+}
+
+void dsn_destroy(dsn_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& g : ctx->graphs)
+    if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+  for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  for (auto& kv : ctx->ws) (void)hipFree(kv.second.first);
+  delete ctx;
+}
+
+const char* dsn_last_error(const dsn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int dsn_load_tensor(dsn_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim,
+                    int is_device) {
+  return guarded(ctx, [&] {
+    if (!name || !data || ndim < 0 || ndim > 8) fail(DSN_EINVAL, "dsn_load_tensor: bad arguments");
+    DevTensor t;
+    t.numel = 1;
+    for (int i = 0; i < ndim; ++i) {
+      t.shape.push_back(shape[i]);
+      t.numel *= shape[i];
+    }
+    if (t.numel <= 0) fail(DSN_EINVAL, "%s: empty tensor", name);
+    auto it = ctx->raw.find(name);
+    if (it != ctx->raw.end()) {
+      HIPCHK(hipFree(it->second.p));
+      ctx->raw.erase(it);
+    }
+    HIPCHK(hipMalloc((void**)&t.p, sizeof(float) * t.numel));
+    HIPCHK(hipMemcpy(t.p, data, sizeof(float) * t.numel, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    ctx->raw[name] = t;
+    ctx->finalized = false;
+  });
+}
+
+int dsn_finalize_weights(dsn_ctx* ctx) {
+  return guarded(ctx, [&] { ctx->finalize(nullptr); });
+}
+
+int dsn_score(dsn_ctx* ctx, const float* xt, const float* t, const float* mix, float* out, int B, int T,
+              void* stream) {
+  return guarded(ctx, [&] {
+    if (!xt || !t || !mix || !out || B <= 0 || T <= 0) fail(DSN_EINVAL, "dsn_score: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* sc = ctx->score_tokens(xt, t, mix, B, T, st);
+    launch_unpack_tokens(sc, out, B, ctx->cfg.n_src * ctx->cfg.latent_dim, T, st);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+int dsn_ouve_schedule(const dsn_ctx* ctx, int N, float t_eps, float snr, float* timesteps, float* std_,
+                      float* corr_step, float* corr_gain, float* G, float* std_T) {
+  if (!ctx || N <= 0) return DSN_EINVAL;
+  const dsn_ctx::Sched s = ctx->schedule(N, t_eps, snr);
+  for (int i = 0; i < N; ++i) {
+    if (timesteps) timesteps[i] = s.t[i];
+    if (std_) std_[i] = s.std[i];
+    if (corr_step) corr_step[i] = s.step[i];
+    if (corr_gain) corr_gain[i] = s.gain[i];
+    if (G) G[i] = s.G[i];
+  }
+  if (std_T) *std_T = s.stdT;
+  return DSN_OK;
+}
+
+int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N,
+                  int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream) {
+  return guarded(ctx, [&] {
+    if (!y || !x_out || B <= 0 || T <= 0 || N <= 0 || corrector_steps < 0) fail(DSN_EINVAL, "dsn_pc_sample: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long sz = (long)B * ctx->cfg.n_src * ctx->cfg.latent_dim * T;
+    const long draws = 1 + (long)N * (corrector_steps + 1);
+    if (!noise) {
+      float* nz = ctx->wsbuf<float>("pc_noise", sz * draws);
+      launch_randn(nz, sz * draws, seed, 0, st);
+      noise = nz;
+    }
+    float* r = ctx->pc_sample(y, noise, B, T, N, corrector_steps, snr, t_eps, denoise, st);
+    HIPCHK(hipMemcpyAsync(x_out, r, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    if (nfe_out) *nfe_out = N * (corrector_steps + 1);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+int dsn_hop_length(const dsn_ctx* ctx) { return ctx ? ctx->hop() : DSN_EINVAL; }
+
+int dsn_latent_frames(const dsn_ctx* ctx, int L) {
+  if (!ctx || L < 0) return DSN_EINVAL;
+  const int h = ctx->hop();
+  return (L + (h - L % h)) / h;  // reference utils.pad: a full extra hop when L % hop == 0
+}
+
+int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream) {
+  return guarded(ctx, [&] {
+    if (!est || !wav || B <= 0 || T <= 0) fail(DSN_EINVAL, "dsn_decode: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = B * ctx->cfg.n_src;
+    const long Lfull = (long)ctx->hop() * T;
+    const long Lt = target_len > 0 ? target_len : Lfull;
+    if (Lt > Lfull) fail(DSN_EINVAL, "target_len %ld > decoded length %ld", Lt, Lfull);
+    float* w = ctx->decode(est, S, T, st);
+    HIPCHK(hipMemcpy2DAsync(wav, sizeof(float) * Lt, w, sizeof(float) * Lfull, sizeof(float) * Lt, S,
+                            hipMemcpyDeviceToDevice, st));
+  });
+}
+
+int dsn_encode(dsn_ctx* ctx, const float* mix, const float* vae_noise, uint64_t seed, float* y, int B, int L,
+               void* stream) {
+  return guarded(ctx, [&] {
+    if (!mix || !y || B <= 0 || L < 0) fail(DSN_EINVAL, "dsn_encode: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int h = ctx->hop();
+    const int T = dsn_latent_frames(ctx, L);
+    const long Lp = (long)T * h;
+    float* padded = ctx->wsbuf<float>("enc_wav", (long)B * Lp);
+    HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * B * Lp, st));
+    if (L > 0)
+      HIPCHK(hipMemcpy2DAsync(padded, sizeof(float) * Lp, mix, sizeof(float) * L, sizeof(float) * L, B,
+                              hipMemcpyDeviceToDevice, st));
+    const long nsz = (long)B * ctx->cfg.latent_dim * T;
+    if (!vae_noise) {
+      float* nz = ctx->wsbuf<float>("enc_noise", nsz);
+      launch_randn(nz, nsz, seed ^ 0x5851F42D4C957F2DULL, 0, st);
+      vae_noise = nz;
+    }
+    ctx->encode(padded, vae_noise, y, B, (int)Lp, st);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const float* noise, uint64_t seed,
+                 float* wav, int B, int L, int target_len, int N, int corrector_steps, float snr, float t_eps,
+                 int denoise, int* nfe_out, void* stream) {
+  if (!ctx) return DSN_EINVAL;
+  const int T = dsn_latent_frames(ctx, L);
+  int rc = DSN_OK;
+  float* y = nullptr;
+  float* x = nullptr;
+  rc = guarded(ctx, [&] {
+    const long ysz = (long)B * ctx->cfg.latent_dim * T;
+    y = ctx->wsbuf<float>("sep_y", ysz);
+    x = ctx->wsbuf<float>("sep_x", ysz * ctx->cfg.n_src);
+  });
+  if (rc) return rc;
+  if ((rc = dsn_encode(ctx, mix, vae_noise, seed, y, B, L, stream))) return rc;
+  if ((rc = dsn_pc_sample(ctx, y, noise, seed + 1, x, B, T, N, corrector_steps, snr, t_eps, denoise, nfe_out, stream)))
+    return rc;
+  return dsn_decode(ctx, x, wav, B, T, target_len > 0 ? target_len : L, stream);
+}
+
+int dsn_enable_graphs(dsn_ctx* ctx, int enable) {
+  if (!ctx) return DSN_EINVAL;
+  ctx->use_graphs = enable != 0;
+  return DSN_OK;
+}
+
+int64_t dsn_workspace_bytes(const dsn_ctx* ctx) { return ctx ? ctx->ws_bytes() : 0; }
+
+int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N, int taps,
+                   int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream) {
+  return guarded(ctx, [&] {
+    hipStream_t st = (hipStream_t)stream;
+    const int P = ctx->P;
+    const long an = (long)B * Lin * Cin, wn = (long)N * taps * Cin;
+    bf16_t* ap = ctx->wsbuf<bf16_t>("t_a", an * P);
+    bf16_t* wp = ctx->wsbuf<bf16_t>("t_w", wn * P);
+    launch_to_planes(a, ap, an, P, an, st);
+    launch_to_planes(w, wp, wn, P, wn, st);
+    Packed pk;
+    pk.w = wp;
+    pk.ps = wn;
+    pk.N = N;
+    pk.Cin = Cin;
+    pk.taps = taps;
+    pk.K = taps * Cin;
+    GemmDesc d = ctx->base_desc(ap, an, pk, B, rows_per_b, Lin);
+    d.in_stride = in_stride;
+    d.tap_dil = tap_dil;
+    d.in_pad = in_pad;
+    d.out_f32 = out;
+    ctx->run(d, st);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

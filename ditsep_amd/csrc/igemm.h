@@ -1,0 +1,47 @@
+// Implicit-GEMM descriptor shared by the engine and the MFMA kernel.
+//
+// One kernel family serves every dense contraction on the path:
+//   Linear (DiT QKV / out-proj / FF), 1x1 conv, dilated k=7 Conv1d,
+//   strided Conv1d (Oobleck encoder), ConvTranspose1d (as 2-tap phase GEMM).
+// Activations are channels-last ("token-major"): row = (batch item, position),
+// columns = channels, stored as P bf16 planes (common.h).  Weights are packed
+// [N][taps*Cin] K-major, same planes.
+//
+//   out[b, j, n] = sum_{tap, ci} W[n][tap*Cin + ci] * A[b][j*in_stride + tap*tap_dil - in_pad][ci]
+//
+// with zero fill outside [0, Lin).  GEMM row m = b*rows_per_b + j.
+// Output element offset = b*out_bstride + j*out_row_elems + out_off + n, stored
+// only when 0 <= j*out_row_elems + out_off + n < out_limit (ConvTranspose1d
+// phase clipping; prepend-token row shifts).
+#pragma once
+#include "common.h"
+
+struct GemmDesc {
+  const bf16_t* A;
+  long a_ps;  // plane stride of A (elements)
+  const bf16_t* W;
+  long w_ps;  // plane stride of W
+  int M, N, Cin, taps;
+  int rows_per_b, Lin, in_stride, tap_dil, in_pad;
+  long in_bstride;  // elements per batch item of A (normally Lin*Cin)
+  long out_bstride;
+  int out_row_elems, out_off;
+  long out_limit;
+  const float* bias;  // [bias_mod] or null; indexed n % bias_mod (packed order when swiglu)
+  int bias_mod;
+  const float* resid;  // fp32, same addressing as out, or null
+  float* out_f32;      // or null
+  int f32_op;          // DSN_F32_*
+  float out_scale;     // applied after bias + residual
+  bf16_t* out_planes;  // or null: act(out) written as P planes
+  long out_ps;
+  int act;             // DSN_ACT_*
+  const float* act_a;  // snake alpha   (exp applied) [act_mod]
+  const float* act_b;  // snake 1/(beta+1e-9)         [act_mod]
+  int act_mod;
+  int swiglu;          // packed N holds (value16, gate16) interleaved groups; N_out = N/2
+  int tiles_m, tiles_n;
+};
+
+// launchers (igemm.hip)
+hipError_t igemm_launch(const GemmDesc& d, int planes, hipStream_t stream);

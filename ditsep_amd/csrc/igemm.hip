@@ -1,0 +1,253 @@
+// Implicit-GEMM MFMA kernel for gfx950 (see igemm.h for the contraction).
+//
+// Tile 128(m) x 128(n) x 32(k) per 256-thread workgroup (4 waves as 2x2, each
+// wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators).  Operands are
+// swapped on the matrix core: MFMA-A = weight rows (n), MFMA-B = activation
+// rows (m), so each lane ends up holding FOUR CONSECUTIVE CHANNELS of one
+// output row -> 16-byte fp32 / 8-byte bf16 channels-last stores and in-lane
+// bias / activation / SwiGLU epilogues.
+//
+// K loop: taps outer, channel chunks inner; every (tap, chunk) stages a
+// [128][32] activation tile whose rows are the tap-shifted input rows
+// (zero-filled outside the sequence) and the matching weight tile.  Global ->
+// register -> LDS staging, LDS double buffered, one barrier per k-tile: the
+// loads of tile t+1 are issued before the MFMAs of tile t and written to the
+// other buffer after them.
+// LDS rows are 64 B; the 16-byte chunk index is XOR-swizzled with
+// (-(row>>2))&3 so that every 16-lane ds_read_b128 group touches 16 distinct
+// 16-byte slots of the 256-byte bank row.
+#include "igemm.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_ELEMS = 128 * BK;  // one operand plane tile
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+
+template <int P>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
+  // [buf][operand A=0/W=1][plane][row*32 + chunk*8]
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * P * TILE_ELEMS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware, bijective tile remap: blocks b and b+8 share an XCD (L2); give
+  // each XCD a contiguous run of tiles with tile_n fastest so the blocks that
+  // re-read one activation row panel sit behind the same L2.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = t / d.tiles_n, tile_n = t - tile_m * d.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int Ktot = d.taps * d.Cin;
+  const int kc_per_tap = d.Cin / BK;
+  const int nkt = d.taps * kc_per_tap;
+
+  // ---- staging assignment: 2 chunks of A and 2 of W per plane per thread ----
+  int s_row[2], s_kch[2], s_lds[2];
+  long a_base[2];
+  int a_js[2];
+  bool a_ok[2], w_ok[2];
+  long w_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;
+    const int row = c >> 2, kch = c & 3;
+    s_row[i] = row;
+    s_kch[i] = kch;
+    s_lds[i] = row * BK + swz(row, kch) * 8;
+    const int m = m0 + row;
+    const int b = m / d.rows_per_b;
+    const int j = m - b * d.rows_per_b;
+    a_ok[i] = m < d.M;
+    a_base[i] = (long)b * d.in_bstride + kch * 8;
+    a_js[i] = j * d.in_stride - d.in_pad;
+    const int n = n0 + row;
+    w_ok[i] = n < d.N;
+    w_base[i] = (long)n * Ktot + kch * 8;
+  }
+
+  bf16x8 ra[P][2], rw[P][2];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto stage_load = [&](int kt) {
+    const int tap = kt / kc_per_tap;
+    const int kc = kt - tap * kc_per_tap;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = a_js[i] + tap * d.tap_dil;
+      const bool ok = a_ok[i] && r >= 0 && r < d.Lin;
+      const long aoff = a_base[i] + (long)r * d.Cin + kc * BK;
+      const long woff = w_base[i] + (long)tap * d.Cin + kc * BK;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        ra[p][i] = ok ? *reinterpret_cast<const bf16x8*>(d.A + p * d.a_ps + aoff) : zero8;
+        rw[p][i] = w_ok[i] ? *reinterpret_cast<const bf16x8*>(d.W + p * d.w_ps + woff) : zero8;
+      }
+    }
+  };
+  auto stage_store = [&](int buf) {
+    bf16_t* base = lds + buf * (2 * P * TILE_ELEMS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        *reinterpret_cast<bf16x8*>(base + (0 * P + p) * TILE_ELEMS + s_lds[i]) = ra[p][i];
+        *reinterpret_cast<bf16x8*>(base + (1 * P + p) * TILE_ELEMS + s_lds[i]) = rw[p][i];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (elements) inside a plane tile
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int fsw = swz(frow, fchunk) * 8;  // (tile*16 + wave offset) is a multiple of 16 -> swizzle depends on frow only
+  const int a_frag_off = (wm * 64 + frow) * BK + fsw;
+  const int w_frag_off = (wn * 64 + frow) * BK + fsw;
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage_load(kt + 1);
+
+    const bf16_t* base = lds + buf * (2 * P * TILE_ELEMS);
+    bf16x8 fa[P][4], fw[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[p][i] = *reinterpret_cast<const bf16x8*>(base + (0 * P + p) * TILE_ELEMS + a_frag_off + i * 16 * BK);
+        fw[p][i] = *reinterpret_cast<const bf16x8*>(base + (1 * P + p) * TILE_ELEMS + w_frag_off + i * 16 * BK);
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        if (P == 2) {
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P - 1][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[P - 1][tm], acc[tn][tm], 0, 0, 0);
+        }
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------- epilogue ---------------------------------
+  const int nq = (lane >> 4) * 4;  // first of this lane's 4 consecutive channels inside a 16-tile
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+    if (m >= d.M) continue;
+    const int b = m / d.rows_per_b;
+    const int j = m - b * d.rows_per_b;
+    const long row_rel = (long)j * d.out_row_elems + d.out_off;
+    const long row_abs = (long)b * d.out_bstride + row_rel;
+    if (!d.swiglu) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wn * 64 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const long rel = row_rel + n;
+        if (rel < 0 || rel >= d.out_limit) continue;
+        const long off = row_abs + n;
+        f32x4 v = acc[tn][tm];
+        if (d.bias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+          v += bb;
+        }
+        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
+        v *= d.out_scale;
+        if (d.out_f32) {
+          f32x4 o = v;
+          if (d.f32_op == DSN_F32_TANH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
+          }
+          *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
+        }
+        if (d.out_planes) {
+          f32x4 a = v;
+          if (d.act == DSN_ACT_ELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_elu(v[r]);
+          } else if (d.act == DSN_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_silu(v[r]);
+          } else if (d.act == DSN_ACT_SNAKE) {
+            const int ch = n % d.act_mod;
+            const f32x4 al = *reinterpret_cast<const f32x4*>(d.act_a + ch);
+            const f32x4 ib = *reinterpret_cast<const f32x4*>(d.act_b + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
+          }
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bf16_t h, l;
+            dsn_split(a[r], h, l);
+            hi[r] = h;
+            lo[r] = l;
+          }
+          *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
+          if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+        }
+      }
+    } else {
+      // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int np = n0 + wn * 64 + tp * 32;  // packed row of the value tile
+        if (np >= d.N) continue;
+        const int feat = (np >> 1) + nq;
+        const long off = row_abs + feat;
+        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
+        if (d.bias) {
+          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
+          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bf16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l);
+          hi[r] = h;
+          lo[r] = l;
+        }
+        *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t igemm_launch(const GemmDesc& din, int planes, hipStream_t stream) {
+  GemmDesc d = din;
+  d.tiles_m = cdiv(d.M, BM);
+  d.tiles_n = cdiv(d.N, BN);
+  if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
+  if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
+  const int grid = d.tiles_m * d.tiles_n;
+  if (planes == 1)
+    hipLaunchKernelGGL(igemm_kernel<1>, dim3(grid), dim3(256), 0, stream, d);
+  else
+    hipLaunchKernelGGL(igemm_kernel<2>, dim3(grid), dim3(256), 0, stream, d);
+  return hipGetLastError();
+}

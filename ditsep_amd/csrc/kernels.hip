@@ -1,0 +1,572 @@
+// Non-GEMM kernels of the separation path for gfx950: layout transforms, the
+// predictor-corrector elementwise updates, LayerNorm, rotary attention for short
+// latent sequences, Oobleck edge convolutions, Philox RNG and weight packing.
+// All are HBM/LDS-bound byte movers: coalesced 16-byte accesses, wave64 shuffles
+// for reductions, no MFMA.
+#include "kernels.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(long n, int per_block = TPB, int cap = 256 * 16) {
+  long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ __forceinline__ void store_planes(bf16_t* dst, long ps, int planes, long i, float v) {
+  bf16_t h, l;
+  dsn_split(v, h, l);
+  dst[i] = h;
+  if (planes == 2) dst[ps + i] = l;
+}
+
+// ------------------------------------------------------------------ transforms
+__global__ void pack_tokens_kernel(const float* __restrict__ s0, int C0, const float* __restrict__ s1, int C1,
+                                   int B, int T, float* __restrict__ df, bf16_t* __restrict__ dp, long ps,
+                                   int planes) {
+  const int C = C0 + C1;
+  const long n = (long)B * T * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const float v = c < C0 ? s0[((long)b * C0 + c) * T + t] : s1[((long)b * C1 + (c - C0)) * T + t];
+    if (df) df[i] = v;
+    if (dp) store_planes(dp, ps, planes, i, v);
+  }
+}
+
+__global__ void unpack_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int T) {
+  const long n = (long)B * C * T;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long bc = i / T;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    dst[i] = src[((long)b * T + t) * C + c];
+  }
+}
+
+__global__ void to_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long ps, int planes,
+                                 long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bf16_t h, l;
+      dsn_split(v[r], h, l);
+      hi[r] = h;
+      lo[r] = l;
+    }
+    reinterpret_cast<bf16x4*>(dst)[i] = hi;
+    if (planes == 2) reinterpret_cast<bf16x4*>(dst + ps)[i] = lo;
+  }
+}
+
+// ------------------------------------------------------------------ PC sampler
+// index helpers for x[B,n,D,T] (i linear), y[B,1,D,T], score token-major [B*T][n*D]
+struct PcIdx {
+  long yi, si;
+};
+__device__ __forceinline__ PcIdx pc_index(long i, int n, int D, int T) {
+  const int t = (int)(i % T);
+  long r = i / T;
+  const int c = (int)(r % D);
+  r /= D;
+  const int s = (int)(r % n);
+  const long b = r / n;
+  PcIdx o;
+  o.yi = (b * D + c) * T + t;
+  o.si = (b * T + t) * ((long)n * D) + (long)s * D + c;
+  return o;
+}
+
+__global__ void pc_prior_kernel(const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ x,
+                                float stdT, int n, int D, int T, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const PcIdx ix = pc_index(i, n, D, T);
+    x[i] = y[ix.yi] + z[i] * stdT;
+  }
+}
+
+__global__ void pc_corrector_kernel(float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ z,
+                                    float step, float gain, int n, int D, int T, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const PcIdx ix = pc_index(i, n, D, T);
+    const float xm = x[i] + step * sc[ix.si];
+    x[i] = xm + z[i] * gain;
+  }
+}
+
+__global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ xmean, const float* __restrict__ y,
+                                    const float* __restrict__ sc, const float* __restrict__ z, float theta,
+                                    float dt, float G, int n, int D, int T, long total) {
+  const float G2 = G * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const PcIdx ix = pc_index(i, n, D, T);
+    const float xv = x[i];
+    const float f = theta * (y[ix.yi] - xv) * dt;
+    const float rev = f - G2 * sc[ix.si];
+    const float xm = xv - rev;
+    xmean[i] = xm;
+    x[i] = xm + G * z[i];
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// one wave per row, float4 per lane per pass
+__global__ void layernorm_planes_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, bf16_t* __restrict__ out, long ps,
+                                        int planes, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * D);
+    const int nv = D >> 2;
+    float s = 0.f;
+    for (int i = lane; i < nv; i += 64) {
+      const f32x4 v = xr[i];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int i = lane; i < nv; i += 64) {
+      const f32x4 v = xr[i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dlt = v[r] - mean;
+        q += dlt * dlt;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    for (int i = lane; i < nv; i += 64) {
+      const f32x4 v = xr[i];
+      const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (v[r] - mean) * rstd * g[r];
+      if (beta) {
+        const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[i];
+        o += bb;
+      }
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf16_t h, l;
+        dsn_split(o[r], h, l);
+        hi[r] = h;
+        lo[r] = l;
+      }
+      const long oi = ((long)row * D >> 2) + i;
+      reinterpret_cast<bf16x4*>(out)[oi] = hi;
+      if (planes == 2) reinterpret_cast<bf16x4*>(out + ps)[oi] = lo;
+    }
+  }
+}
+
+__global__ void timestep_features_kernel(const float* __restrict__ t, const float* __restrict__ w, int B, int half,
+                                         bf16_t* __restrict__ out, long ps, int planes) {
+  const int n = B * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int b = i / half, k = i - b * half;
+    const float f = 2.f * 3.14159265358979323846f * t[b] * w[k];
+    store_planes(out, ps, planes, (long)b * 2 * half + k, cosf(f));
+    store_planes(out, ps, planes, (long)b * 2 * half + half + k, sinf(f));
+  }
+}
+
+__global__ void rope_tables_kernel(float* __restrict__ ct, float* __restrict__ st, int S, int rot) {
+  const int half = rot / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * rot; i += gridDim.x * blockDim.x) {
+    const int p = i / rot, d = i - p * rot;
+    const int k = d % half;
+    const float inv = 1.0f / powf(10000.0f, (float)(2 * k) / (float)rot);
+    const float f = (float)p * inv;
+    ct[i] = cosf(f);
+    st[i] = sinf(f);
+  }
+}
+
+// ------------------------------------------------------------------ attention
+// One workgroup per (batch item, head); K (rotary applied) and V of the whole
+// sequence live in LDS (S <= 256); each wave owns one query at a time: lane = key
+// for q.k^T (K rows padded to DH+4 floats -> conflict-free ds_read_b128), wave
+// shuffles for the softmax statistics, lane = feature for P.V.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+                                                        const float* __restrict__ rcos,
+                                                        const float* __restrict__ rsin, int rot,
+                                                        bf16_t* __restrict__ out, long ps, int planes, int S,
+                                                        int H) {
+  static_assert(DH == 64, "lane = feature mapping assumes 64-wide heads");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KS = DH + 4;
+  float* Ks = smem;           // [S][KS]
+  float* Vs = smem + S * KS;  // [S][DH]
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int Dm = H * DH;
+  const long rowstride = 3L * Dm;
+  const float* base = qkv + (long)b * S * rowstride + h * DH;
+  const int half = rot >> 1;
+
+  for (int i = threadIdx.x; i < S * DH; i += blockDim.x) {
+    const int kj = i / DH, d = i - kj * DH;
+    const float* kr = base + (long)kj * rowstride + Dm;
+    float kv = kr[d];
+    if (d < rot) {
+      const float partner = d < half ? -kr[d + half] : kr[d - half];
+      kv = kv * rcos[kj * rot + d] + partner * rsin[kj * rot + d];
+    }
+    Ks[kj * KS + d] = kv;
+    Vs[kj * DH + d] = base[(long)kj * rowstride + 2 * Dm + d];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float scale = rsqrtf((float)DH);
+  const int nchunk = (S + 63) >> 6;
+  for (int qi = wave; qi < S; qi += nw) {
+    // q row: lane = feature, rotary via lane exchange, pre-scaled
+    float qv = base[(long)qi * rowstride + lane];
+    {
+      const int pl = lane < half ? lane + half : lane - half;
+      const float pv = __shfl(qv, pl & 63, 64);
+      if (lane < rot) {
+        const float partner = lane < half ? -pv : pv;
+        qv = qv * rcos[qi * rot + lane] + partner * rsin[qi * rot + lane];
+      }
+    }
+    qv *= scale;
+    float m_run = -INFINITY, l_run = 0.f, o_acc = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      const int kj = c * 64 + lane;
+      const bool valid = kj < S;
+      const float* krow = Ks + (valid ? kj : 0) * KS;
+      float sdot = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < DH / 4; ++d4) {
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(krow + d4 * 4);
+        sdot += kk[0] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 0));
+        sdot += kk[1] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 1));
+        sdot += kk[2] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 2));
+        sdot += kk[3] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 3));
+      }
+      const float sv = valid ? sdot : -INFINITY;
+      const float m_new = fmaxf(m_run, wave_max(sv));
+      const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first chunk
+      const float p = valid ? __expf(sv - m_new) : 0.f;
+      l_run = l_run * alpha + wave_sum(p);
+      o_acc *= alpha;
+      const int kmax = min(64, S - c * 64);
+      const float* vcol = Vs + (long)c * 64 * DH + lane;
+      for (int jj = 0; jj < kmax; ++jj) {
+        const float pj = __shfl(p, jj, 64);
+        o_acc += pj * vcol[jj * DH];
+      }
+      m_run = m_new;
+    }
+    const float o = o_acc / l_run;
+    store_planes(out, ps, planes, ((long)b * S + qi) * Dm + h * DH + lane, o);
+  }
+}
+
+// ------------------------------------------------------------------ Oobleck edges
+// Cout == 1 convolution over already-activated planes: 64 outputs per workgroup,
+// (64 + ktaps - 1) rows staged in LDS (fp32, rows padded by 4 floats), 4 channel
+// quarters reduced through LDS.
+__global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict__ a, long ps, int planes,
+                                                        const float* __restrict__ w, float* __restrict__ out,
+                                                        int L, int C, int ktaps, int apply_tanh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RS = C + 4;
+  const int nrows = 64 + ktaps - 1;
+  float* rows = smem;              // [nrows][RS]
+  float* wl = rows + nrows * RS;   // [ktaps][C]
+  float* part = wl + ktaps * C;    // [4][64]
+  const int blocks_per_seq = (L + 63) / 64;
+  const int s = blockIdx.x / blocks_per_seq;
+  const int l0 = (blockIdx.x - s * blocks_per_seq) * 64;
+  const int pad = (ktaps - 1) / 2;
+  const int c8 = C / 8;
+  for (int i = threadIdx.x; i < nrows * c8; i += blockDim.x) {
+    const int r = i / c8, ch = (i - r * c8) * 8;
+    const int l = l0 - pad + r;
+    float v[8];
+    if (l >= 0 && l < L) {
+      const long gi = ((long)s * L + l) * C + ch;
+      const bf16x8 hi = *reinterpret_cast<const bf16x8*>(a + gi);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (float)hi[k];
+      if (planes == 2) {
+        const bf16x8 lo = *reinterpret_cast<const bf16x8*>(a + ps + gi);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)lo[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[r * RS + ch + k] = v[k];
+  }
+  for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const int pos = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const int cw = C / 4;
+  float acc = 0.f;
+  for (int t = 0; t < ktaps; ++t) {
+    const float* rr = rows + (pos + t) * RS + cq * cw;
+    const float* ww = wl + t * C + cq * cw;
+    for (int c = 0; c < cw; c += 4) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(rr + c);
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(ww + c);
+      acc += x4[0] * w4[0] + x4[1] * w4[1] + x4[2] * w4[2] + x4[3] * w4[3];
+    }
+  }
+  part[cq * 64 + pos] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int l = l0 + threadIdx.x;
+    if (l < L) {
+      float v = (part[threadIdx.x] + part[64 + threadIdx.x]) + (part[128 + threadIdx.x] + part[192 + threadIdx.x]);
+      out[(long)s * L + l] = apply_tanh ? tanhf(v) : v;
+    }
+  }
+}
+
+__global__ void conv_in1_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                const float* __restrict__ bias, int L, int Cout, int ktaps,
+                                float* __restrict__ of, bf16_t* __restrict__ op, long ps, int planes, int act,
+                                const float* __restrict__ aa, const float* __restrict__ ab, long total) {
+  const int pad = (ktaps - 1) / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const long sl = i / Cout;
+    const int l = (int)(sl % L);
+    const long s = sl / L;
+    float acc = bias ? bias[co] : 0.f;
+    for (int t = 0; t < ktaps; ++t) {
+      const int li = l + t - pad;
+      if (li >= 0 && li < L) acc += w[co * ktaps + t] * wav[s * L + li];
+    }
+    if (of) of[i] = acc;
+    if (op) {
+      float a = acc;
+      if (act == DSN_ACT_ELU) a = dsn_elu(acc);
+      else if (act == DSN_ACT_SNAKE) a = dsn_snake(acc, aa[co], ab[co]);
+      store_planes(op, ps, planes, i, a);
+    }
+  }
+}
+
+__global__ void vae_sample_kernel(const float* __restrict__ enc, const float* __restrict__ noise,
+                                  float* __restrict__ y, int D, int T, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long sc = i / T;
+    const int c = (int)(sc % D);
+    const long s = sc / D;
+    const float* row = enc + (s * T + t) * (2L * D);
+    const float mean = row[c], scale = row[D + c];
+    const float sp = scale > 20.f ? scale : log1pf(expf(scale));
+    y[i] = noise[i] * (sp + 1e-4f) + mean;
+  }
+}
+
+// ------------------------------------------------------------------ RNG
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void randn_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned long long offset) {
+  const long n4 = (n + 3) >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long ctr = (unsigned long long)i + offset;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = ((float)(c[r] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float z[4];
+    const float r0 = sqrtf(-2.f * logf(u[0])), r1 = sqrtf(-2.f * logf(u[2]));
+    const float tw = 6.283185307179586f;
+    z[0] = r0 * cosf(tw * u[1]);
+    z[1] = r0 * sinf(tw * u[1]);
+    z[2] = r1 * cosf(tw * u[3]);
+    z[3] = r1 * sinf(tw * u[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (i * 4 + r < n) out[i * 4 + r] = z[r];
+  }
+}
+
+// ------------------------------------------------------------------ weight packing
+__global__ void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ scale,
+                                int R, long inner) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float s = 0.f;
+  for (long i = lane; i < inner; i += 64) {
+    const float x = v[(long)row * inner + i];
+    s += x * x;
+  }
+  s = wave_sum(s);
+  if (lane == 0) scale[row] = g[row] / sqrtf(s);
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                   bf16_t* __restrict__ dst, long ps, int planes, int mode, int N, int K,
+                                   int Cin, int Cout, int kw, int stride) {
+  const long total = (long)N * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    float v;
+    if (mode == PACK_LINEAR) {
+      v = src[(long)n * K + k];
+    } else if (mode == PACK_LINEAR_SWIGLU) {
+      const int F = N / 2, g = n >> 5, w = n & 31;
+      const int srow = w < 16 ? 16 * g + w : F + 16 * g + (w - 16);
+      v = src[(long)srow * K + k];
+    } else if (mode == PACK_CONV) {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      v = src[((long)n * Cin + ci) * kw + tap];
+      if (scale) v *= scale[n];
+    } else {  // PACK_CONVT: n = phase*Cout + co ; k = tap*Cin + ci ; kernel index = phase + tap*stride
+      const int p = n / Cout, co = n - p * Cout;
+      const int tap = k / Cin, ci = k - tap * Cin;
+      v = src[((long)ci * Cout + co) * kw + (p + tap * stride)];
+      if (scale) v *= scale[ci];
+    }
+    store_planes(dst, ps, planes, i, v);
+  }
+}
+
+__global__ void pack_bias_swiglu_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
+  const int F = N / 2;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const int g = n >> 5, w = n & 31;
+    dst[n] = src[w < 16 ? 16 * g + w : F + 16 * g + (w - 16)];
+  }
+}
+
+__global__ void snake_params_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
+                                    float* __restrict__ a, float* __restrict__ ib, int C) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) {
+    a[i] = expf(alpha[i]);
+    ib[i] = 1.0f / (expf(beta[i]) + 1e-9f);
+  }
+}
+
+}  // namespace
+
+// =========================================================================== launchers
+void launch_pack_tokens(const float* s0, int C0, const float* s1, int C1, int B, int T, float* df, bf16_t* dp,
+                        long ps, int planes, hipStream_t st) {
+  const long n = (long)B * T * (C0 + C1);
+  hipLaunchKernelGGL(pack_tokens_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, s0, C0, s1, C1, B, T, df, dp, ps,
+                     planes);
+}
+void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hipStream_t st) {
+  hipLaunchKernelGGL(unpack_tokens_kernel, dim3(grid_for((long)B * C * T)), dim3(TPB), 0, st, src, dst, B, C, T);
+}
+void launch_to_planes(const float* src, bf16_t* dst, long ps, int planes, long n, hipStream_t st) {
+  hipLaunchKernelGGL(to_planes_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, st, src, dst, ps, planes, n / 4);
+}
+void launch_pc_prior(const float* y, const float* z, float* x, float stdT, int B, int n, int D, int T,
+                     hipStream_t st) {
+  const long total = (long)B * n * D * T;
+  hipLaunchKernelGGL(pc_prior_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, y, z, x, stdT, n, D, T, total);
+}
+void launch_pc_corrector(float* x, const float* sc, const float* z, float step, float gain, int B, int n, int D,
+                         int T, hipStream_t st) {
+  const long total = (long)B * n * D * T;
+  hipLaunchKernelGGL(pc_corrector_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, sc, z, step, gain, n, D, T,
+                     total);
+}
+void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, const float* z, float theta,
+                         float dt, float G, int B, int n, int D, int T, hipStream_t st) {
+  const long total = (long)B * n * D * T;
+  hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G,
+                     n, D, T, total);
+}
+void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, bf16_t* out, long ps,
+                             int planes, int rows, int D, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_planes_kernel, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, gamma, beta, out, ps,
+                     planes, rows, D, eps);
+}
+void launch_timestep_features(const float* t, const float* w, int B, int half, bf16_t* out, long ps, int planes,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(timestep_features_kernel, dim3(grid_for((long)B * half)), dim3(TPB), 0, st, t, w, B, half,
+                     out, ps, planes);
+}
+void launch_rope_tables(float* ct, float* stb, int S, int rot, hipStream_t st) {
+  hipLaunchKernelGGL(rope_tables_kernel, dim3(grid_for((long)S * rot)), dim3(TPB), 0, st, ct, stb, S, rot);
+}
+void launch_attention(const float* qkv, const float* rc, const float* rs, int rot, bf16_t* out, long ps,
+                      int planes, int B, int S, int H, int dh, hipStream_t st) {
+  (void)dh;
+  const size_t sm = (size_t)S * (64 + 4 + 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_kernel<64>, dim3(B * H), dim3(TPB), sm, st, qkv, rc, rs, rot, out, ps, planes, S, H);
+}
+void launch_conv_out1(const bf16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
+                      int ktaps, int apply_tanh, hipStream_t st) {
+  const size_t sm = ((size_t)(64 + ktaps - 1) * (C + 4) + (size_t)ktaps * C + 256) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out1_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int blocks = S * ((L + 63) / 64);
+  hipLaunchKernelGGL(conv_out1_kernel, dim3(blocks), dim3(TPB), sm, st, a, ps, planes, w, out, L, C, ktaps,
+                     apply_tanh);
+}
+void launch_conv_in1(const float* wav, const float* w, const float* bias, int S, int L, int Cout, int ktaps,
+                     float* of, bf16_t* op, long ps, int planes, int act, const float* aa, const float* ab,
+                     hipStream_t st) {
+  const long total = (long)S * L * Cout;
+  hipLaunchKernelGGL(conv_in1_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, wav, w, bias, L, Cout, ktaps, of, op,
+                     ps, planes, act, aa, ab, total);
+}
+void launch_vae_sample(const float* enc, const float* noise, float* y, int S, int D, int T, hipStream_t st) {
+  const long total = (long)S * D * T;
+  hipLaunchKernelGGL(vae_sample_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, enc, noise, y, D, T, total);
+}
+void launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t st) {
+  hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(TPB), 0, st, out, n, seed, offset);
+}
+void launch_wn_scale(const float* v, const float* g, float* scale, int R, long inner, hipStream_t st) {
+  hipLaunchKernelGGL(wn_scale_kernel, dim3(cdiv(R, 4)), dim3(TPB), 0, st, v, g, scale, R, inner);
+}
+void launch_pack_weight(const float* src, const float* scale, bf16_t* dst, long ps, int planes, int mode, int N,
+                        int K, int Cin, int Cout, int kw, int stride, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)N * K)), dim3(TPB), 0, st, src, scale, dst, ps, planes,
+                     mode, N, K, Cin, Cout, kw, stride);
+}
+void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t st) {
+  hipLaunchKernelGGL(pack_bias_swiglu_kernel, dim3(grid_for(N)), dim3(TPB), 0, st, src, dst, N);
+}
+void launch_snake_params(const float* alpha, const float* beta, float* a, float* ib, int C, hipStream_t st) {
+  hipLaunchKernelGGL(snake_params_kernel, dim3(grid_for(C)), dim3(TPB), 0, st, alpha, beta, a, ib, C);
+}

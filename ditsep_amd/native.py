@@ -1,0 +1,248 @@
+"""ctypes binding of libditsep_hip.so (C-ABI: include/ditsep_hip.h).
+
+The HIP library is the product; this module only marshals torch device tensors
+(raw pointers + the current HIP stream) across the C boundary.  There is no
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Mapping, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libditsep_hip.so")
+
+PREC_BF16 = 1
+PREC_BF16X3 = 2
+SCORE_NONE, SCORE_DIT, SCORE_NCSNPP = 0, 1, 2
+MAX_VAE_BLOCKS = 8
+
+EXPORTS = [
+    "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
+    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
+    "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
+    "dsn_workspace_bytes", "dsn_test_igemm",
+]
+
+
+class DsnConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("precision", C.c_int32), ("n_src", C.c_int32), ("latent_dim", C.c_int32),
+        ("score_kind", C.c_int32), ("dit_embed_dim", C.c_int32), ("dit_depth", C.c_int32),
+        ("dit_heads", C.c_int32),
+        ("vae_channels", C.c_int32), ("vae_n_blocks", C.c_int32),
+        ("vae_c_mults", C.c_int32 * MAX_VAE_BLOCKS), ("vae_strides", C.c_int32 * MAX_VAE_BLOCKS),
+        ("vae_enc_latent_dim", C.c_int32), ("vae_use_snake", C.c_int32), ("vae_final_tanh", C.c_int32),
+        ("vae_has_encoder", C.c_int32), ("vae_has_decoder", C.c_int32),
+        ("sde_theta", C.c_float), ("sde_sigma_min", C.c_float), ("sde_sigma_max", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; loud failure when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C ditsep_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cf, fp = C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_float)
+    lib.dsn_create.restype = vp
+    lib.dsn_create.argtypes = [C.POINTER(DsnConfig)]
+    lib.dsn_destroy.restype = None
+    lib.dsn_destroy.argtypes = [vp]
+    lib.dsn_last_error.restype = C.c_char_p
+    lib.dsn_last_error.argtypes = [vp]
+    lib.dsn_load_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci, ci]
+    lib.dsn_finalize_weights.argtypes = [vp]
+    lib.dsn_score.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.dsn_ouve_schedule.argtypes = [vp, ci, cf, cf, fp, fp, fp, fp, fp, fp]
+    lib.dsn_pc_sample.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, cf, cf, ci, C.POINTER(ci), vp]
+    lib.dsn_decode.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    lib.dsn_encode.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, vp]
+    lib.dsn_latent_frames.argtypes = [vp, ci]
+    lib.dsn_hop_length.argtypes = [vp]
+    lib.dsn_separate.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, ci, cf, cf, ci,
+                                 C.POINTER(ci), vp]
+    lib.dsn_enable_graphs.argtypes = [vp, ci]
+    lib.dsn_workspace_bytes.restype = C.c_int64
+    lib.dsn_workspace_bytes.argtypes = [vp]
+    lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("dsn_latent_frames", "dsn_hop_length"):
+            pass
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One native context on one GPU."""
+
+    def __init__(self, *, device: int = 0, precision: int = PREC_BF16X3, n_src: int = 2, latent_dim: int = 64,
+                 score_kind: int = SCORE_DIT, dit_embed_dim: int = 1024, dit_depth: int = 24,
+                 dit_heads: int = 16, vae_channels: int = 128, vae_c_mults=(1, 2, 4, 8, 16),
+                 vae_strides=(2, 4, 4, 8, 8), vae_enc_latent_dim: int = 128, vae_use_snake: bool = False,
+                 vae_final_tanh: bool = True, vae_has_encoder: bool = True, vae_has_decoder: bool = True,
+                 sde_theta: float = 1.5, sde_sigma_min: float = 0.96, sde_sigma_max: float = 10.0):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ditsep_amd needs a ROCm GPU (torch.cuda.is_available() is False)")
+        cfg = DsnConfig()
+        cfg.device, cfg.precision, cfg.n_src, cfg.latent_dim = device, precision, n_src, latent_dim
+        cfg.score_kind = score_kind
+        cfg.dit_embed_dim, cfg.dit_depth, cfg.dit_heads = dit_embed_dim, dit_depth, dit_heads
+        cfg.vae_channels, cfg.vae_n_blocks = vae_channels, len(vae_c_mults)
+        assert len(vae_c_mults) == len(vae_strides) <= MAX_VAE_BLOCKS
+        for i, (m, s) in enumerate(zip(vae_c_mults, vae_strides)):
+            cfg.vae_c_mults[i], cfg.vae_strides[i] = int(m), int(s)
+        cfg.vae_enc_latent_dim = vae_enc_latent_dim
+        cfg.vae_use_snake, cfg.vae_final_tanh = int(vae_use_snake), int(vae_final_tanh)
+        cfg.vae_has_encoder, cfg.vae_has_decoder = int(vae_has_encoder), int(vae_has_decoder)
+        cfg.sde_theta, cfg.sde_sigma_min, cfg.sde_sigma_max = sde_theta, sde_sigma_min, sde_sigma_max
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.n_src, self.latent_dim = n_src, latent_dim
+        self.ctx = self.lib.dsn_create(C.byref(cfg))
+        if not self.ctx:
+            raise RuntimeError("dsn_create failed: " + self.lib.dsn_last_error(None).decode())
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.dsn_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.dsn_last_error(self.ctx).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], prefix: str = ""):
+        """Feed reference-named tensors (e.g. `score_model.*`, `vae.decoder.*`)."""
+        for k, v in sd.items():
+            if not torch.is_floating_point(v):
+                continue
+            t = v.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.ndim, 1))(*t.shape)
+            self._check(self.lib.dsn_load_tensor(self.ctx, (prefix + k).encode(), C.c_void_p(t.data_ptr()),
+                                                 shape, t.ndim, int(t.is_cuda)), f"dsn_load_tensor({prefix + k})")
+
+    def finalize(self):
+        self._check(self.lib.dsn_finalize_weights(self.ctx), "dsn_finalize_weights")
+
+    # ------------------------------------------------------------------ path
+    def score(self, xt, t, mix):
+        xt, t, mix = (_dev32(a, self.device) for a in (xt, t, mix))
+        B, n, D, T = xt.shape
+        out = torch.empty_like(xt)
+        self._check(self.lib.dsn_score(self.ctx, _ptr(xt), _ptr(t), _ptr(mix), _ptr(out), B, T, self._stream()),
+                    "dsn_score")
+        return out
+
+    def ouve_schedule(self, N: int, t_eps: float, snr: float):
+        arr = [(C.c_float * N)() for _ in range(5)]
+        stdT = C.c_float()
+        self._check(self.lib.dsn_ouve_schedule(self.ctx, N, t_eps, snr, *arr, C.byref(stdT)), "dsn_ouve_schedule")
+        names = ("t", "std", "step", "gain", "G")
+        out = {k: torch.tensor(list(a), dtype=torch.float32) for k, a in zip(names, arr)}
+        out["std_T"] = stdT.value
+        return out
+
+    def pc_sample(self, y, noise=None, *, N=30, corrector_steps=1, snr=0.5, t_eps=0.03, denoise=True, seed=0):
+        y = _dev32(y, self.device)
+        B, _, D, T = y.shape
+        if noise is not None:
+            noise = _dev32(noise, self.device)
+            assert tuple(noise.shape) == (1 + N * (corrector_steps + 1), B, self.n_src, D, T), noise.shape
+        x = torch.empty((B, self.n_src, D, T), device=self.device, dtype=torch.float32)
+        nfe = C.c_int()
+        self._check(self.lib.dsn_pc_sample(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N,
+                                           corrector_steps, snr, t_eps, int(denoise), C.byref(nfe),
+                                           self._stream()), "dsn_pc_sample")
+        return x, nfe.value
+
+    def decode(self, est, target_len: Optional[int] = None):
+        est = _dev32(est, self.device)
+        B, n, D, T = est.shape
+        if n != self.n_src or D != self.latent_dim:
+            raise ValueError(f"est must be [B,{self.n_src},{self.latent_dim},T], got {tuple(est.shape)}")
+        L = target_len if target_len else self.hop_length * T
+        wav = torch.empty((B, n, L), device=self.device, dtype=torch.float32)
+        self._check(self.lib.dsn_decode(self.ctx, _ptr(est), _ptr(wav), B, T, L, self._stream()), "dsn_decode")
+        return wav
+
+    def encode(self, mix, vae_noise=None, seed=0):
+        mix = _dev32(mix, self.device)
+        B, _, L = mix.shape
+        T = self.latent_frames(L)
+        if vae_noise is not None:
+            vae_noise = _dev32(vae_noise, self.device)
+            assert tuple(vae_noise.shape) == (B, self.latent_dim, T)
+        y = torch.empty((B, 1, self.latent_dim, T), device=self.device, dtype=torch.float32)
+        self._check(self.lib.dsn_encode(self.ctx, _ptr(mix), _ptr(vae_noise), seed, _ptr(y), B, L, self._stream()),
+                    "dsn_encode")
+        return y
+
+    def separate(self, mix, *, vae_noise=None, noise=None, seed=0, target_len=None, N=30, corrector_steps=1,
+                 snr=0.5, t_eps=0.03, denoise=True):
+        mix = _dev32(mix, self.device)
+        B, _, L = mix.shape
+        Lt = target_len if target_len else L
+        wav = torch.empty((B, self.n_src, Lt), device=self.device, dtype=torch.float32)
+        nfe = C.c_int()
+        vn = None if vae_noise is None else _dev32(vae_noise, self.device)
+        nz = None if noise is None else _dev32(noise, self.device)
+        self._check(self.lib.dsn_separate(self.ctx, _ptr(mix), _ptr(vn), _ptr(nz), seed, _ptr(wav), B, L, Lt, N,
+                                          corrector_steps, snr, t_eps, int(denoise), C.byref(nfe),
+                                          self._stream()), "dsn_separate")
+        return wav, nfe.value
+
+    @property
+    def hop_length(self) -> int:
+        return self.lib.dsn_hop_length(self.ctx)
+
+    def latent_frames(self, L: int) -> int:
+        return self.lib.dsn_latent_frames(self.ctx, L)
+
+    def enable_graphs(self, on: bool = True):
+        self._check(self.lib.dsn_enable_graphs(self.ctx, int(on)), "dsn_enable_graphs")
+
+    def workspace_bytes(self) -> int:
+        return self.lib.dsn_workspace_bytes(self.ctx)
+
+    def test_igemm(self, a, w, *, taps=1, in_stride=1, tap_dil=1, in_pad=0, rows_per_b=None):
+        """a [B,Lin,Cin] channels-last, w [N, taps*Cin] -> [B, rows_per_b, N] (kernel test hook)."""
+        a, w = _dev32(a, self.device), _dev32(w, self.device)
+        B, Lin, Cin = a.shape
+        N = w.shape[0]
+        rpb = rows_per_b or Lin
+        out = torch.empty((B, rpb, N), device=self.device, dtype=torch.float32)
+        self._check(self.lib.dsn_test_igemm(self.ctx, _ptr(a), _ptr(w), _ptr(out), B, Lin, Cin, N, taps, in_stride,
+                                            tap_dil, in_pad, rpb, self._stream()), "dsn_test_igemm")
+        return out

@@ -1,0 +1,126 @@
+/* C-ABI of libditsep_hip.so -- MI355X (gfx950) latent-diffusion separation engine.
+ *
+ * Drop-in boundary for the hot path of eduardburlacu/DiTSep:
+ *   LatentDiffSep.separate()            reference src/diffsep_latent.py:471-487
+ *   LatentDiffSep.get_pc_sampler()      reference src/diffsep_latent.py:406-469
+ *     -> sdes.get_pc_sampler()          reference src/sdes/__init__.py:133-193
+ *   LatentDiffSep.forward (score net)   reference src/diffsep_latent.py:147-148
+ *   LatentDiffSep.encode / decode       reference src/diffsep_latent.py:107-128
+ *
+ * Conventions: plain pointers and sizes only; every data pointer is a DEVICE
+ * pointer owned by the caller (fp32, contiguous, the reference's own tensor
+ * layouts) unless a parameter says host; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Functions return 0 on success, a negative
+ * DSN_E* code on failure (message via dsn_last_error); no exceptions cross the
+ * boundary.  One context per device; a context is not re-entrant.
+ */
+#ifndef DITSEP_HIP_H
+#define DITSEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSN_OK 0
+#define DSN_EINVAL (-1)   /* bad argument / shape                                  */
+#define DSN_EHIP (-2)     /* HIP runtime error                                     */
+#define DSN_ESTATE (-3)   /* weights missing / not finalized                       */
+#define DSN_ENOMEM (-4)
+
+#define DSN_PREC_BF16 1    /* bf16 MFMA operands, fp32 accumulate                  */
+#define DSN_PREC_BF16X3 2  /* split-bf16 (hi,lo) operands: 3 bf16 MFMAs per product */
+
+#define DSN_SCORE_NONE 0
+#define DSN_SCORE_DIT 1    /* reference src/stable_audio_tools/models/dit.py:12-244  */
+#define DSN_SCORE_NCSNPP 2 /* reference src/models/diffsep/score_models.py:140-186   */
+
+#define DSN_MAX_VAE_BLOCKS 8
+
+typedef struct dsn_ctx dsn_ctx;
+
+typedef struct dsn_config {
+  int32_t device;
+  int32_t precision;   /* DSN_PREC_*                                               */
+  int32_t n_src;       /* config.model.n_speakers                                  */
+  int32_t latent_dim;  /* VAE latent channels (64)                                 */
+  /* score network */
+  int32_t score_kind;  /* DSN_SCORE_*                                              */
+  int32_t dit_embed_dim, dit_depth, dit_heads;
+  /* Oobleck VAE (oobleck_finetune.json keys) */
+  int32_t vae_channels;
+  int32_t vae_n_blocks;                       /* len(c_mults) == len(strides)      */
+  int32_t vae_c_mults[DSN_MAX_VAE_BLOCKS];
+  int32_t vae_strides[DSN_MAX_VAE_BLOCKS];
+  int32_t vae_enc_latent_dim;                 /* encoder out channels (2*latent)   */
+  int32_t vae_use_snake, vae_final_tanh;
+  int32_t vae_has_encoder, vae_has_decoder;
+  /* OUVE SDE (config.model.sde) */
+  float sde_theta, sde_sigma_min, sde_sigma_max;
+} dsn_config;
+
+/* lifecycle */
+dsn_ctx* dsn_create(const dsn_config* cfg);
+void dsn_destroy(dsn_ctx* ctx);
+const char* dsn_last_error(const dsn_ctx* ctx);   /* ctx may be NULL after a failed dsn_create */
+
+/* Weights: one call per state_dict entry, reference key names and layouts
+ * (Lightning checkpoint `state_dict`: `score_model.*`, `vae.decoder.*`,
+ * `vae.encoder.*`; old-style weight norm `weight_g` / `weight_v`;
+ * reference src/diffsep_latent.py:341-392).  `data` is fp32; is_device != 0 when it
+ * is a device pointer.  dsn_finalize_weights folds weight norm, transposes to the
+ * K-major packed MFMA layout and splits into bf16 planes, on the GPU. */
+int dsn_load_tensor(dsn_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim,
+                    int is_device);
+int dsn_finalize_weights(dsn_ctx* ctx);
+
+/* score = score_model(xt, time_cond, mix)      (LatentDiffSep.forward)
+ * xt [B,n_src,D,T], t [B], mix [B,1,D,T] -> out [B,n_src,D,T] */
+int dsn_score(dsn_ctx* ctx, const float* xt, const float* t, const float* mix, float* out, int B, int T,
+              void* stream);
+
+/* OUVE schedule scalars exactly as the sampler uses them (host arrays of N floats each;
+ * any output pointer may be NULL).  timesteps = linspace(1, t_eps, N). */
+int dsn_ouve_schedule(const dsn_ctx* ctx, int N, float t_eps, float snr, float* timesteps, float* std,
+                      float* corr_step, float* corr_gain, float* G, float* std_T);
+
+/* pc_sampler() of sdes.get_pc_sampler("reverse_diffusion", "ald", ...):
+ * y [B,1,D,T] -> x_out [B,n_src,D,T]; nfe_out (host) = N*(corrector_steps+1).
+ * noise: [1 + N*(corrector_steps+1), B, n_src, D, T] standard normals in the reference's
+ * draw order (prior, then per step corrector draws, predictor draw), or NULL to draw
+ * on-device (Philox4x32-10, `seed`). */
+int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
+                  int N, int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream);
+
+/* LatentDiffSep.decode: est [B,n_src,D,T] -> wav [B,n_src,target_len] (crop of hop*T;
+ * target_len <= 0 means hop*T). */
+int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream);
+
+/* LatentDiffSep.encode (mixture branch): mix [B,1,L] -> y [B,1,D,T], T = (L + pad)/hop with
+ * the reference's pad rule (a full extra hop when L % hop == 0).  vae_noise [B,D,T] or NULL
+ * (on-device draw with `seed`). */
+int dsn_encode(dsn_ctx* ctx, const float* mix, const float* vae_noise, uint64_t seed, float* y, int B, int L,
+               void* stream);
+int dsn_latent_frames(const dsn_ctx* ctx, int L);   /* T for an L-sample mixture */
+int dsn_hop_length(const dsn_ctx* ctx);
+
+/* LatentDiffSep.separate(mix, target_dim, latent=False): encode -> sample -> decode.
+ * noise / vae_noise as above (both NULL = on-device RNG). */
+int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const float* noise, uint64_t seed,
+                 float* wav, int B, int L, int target_len, int N, int corrector_steps, float snr, float t_eps,
+                 int denoise, int* nfe_out, void* stream);
+
+/* introspection for benchmarks / tests */
+int dsn_enable_graphs(dsn_ctx* ctx, int enable);          /* hipGraph replay of sample/decode */
+int64_t dsn_workspace_bytes(const dsn_ctx* ctx);
+
+/* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
+ * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */
+int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N,
+                   int taps, int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DITSEP_HIP_H */

@@ -174,12 +174,19 @@ def dit_param_shapes(cfg: DiTConfig) -> dict:
     return s
 
 
-def random_dit_weights(cfg: DiTConfig, seed: int, out_gain: float = 1.0) -> dict:
+def random_dit_weights(cfg: DiTConfig, seed: int, out_gain: float = 1.0,
+                       skip_gain: float = 0.0) -> dict:
     """Seeded re-randomisation of EVERY parameter (the reference's default init
     zeroes to_out / ff-out / pre/post convs, SURVEY.md F5, which would make
     parity vacuous).  Linear weights ~ N(0, 1/fan_in) so activations stay O(1);
     norm gains ~ 1 + 0.1 N(0,1); biases ~ 0.1 N(0,1).  `out_gain` scales
-    project_out so the score magnitude suits the sampler dynamics."""
+    project_out so the score magnitude suits the sampler dynamics.
+
+    `skip_gain` = kappa > 0 adds, through the network's own linear skip path
+    (project_in -> residual stream -> project_out), the term -kappa (x_s - y):
+    the shape of a trained OU score, so that the synthetic sampler contracts
+    towards the mixture like a trained model does instead of random-walking to
+    |x| ~ 100 (no trained weights exist)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for name, shape in dit_param_shapes(cfg).items():
@@ -198,4 +205,13 @@ def random_dit_weights(cfg: DiTConfig, seed: int, out_gain: float = 1.0) -> dict
         if name == "transformer.project_out.weight":
             w = w * out_gain
         sd[name] = w
+    if skip_gain:
+        n, Dl = cfg.n_src, cfg.latent_dim
+        M = torch.zeros(cfg.io_channels, cfg.dim_in)
+        M[:, : cfg.io_channels] = torch.eye(cfg.io_channels)
+        for s_ in range(n):
+            M[s_ * Dl:(s_ + 1) * Dl, cfg.io_channels:] = -torch.eye(Dl)
+        pinv = torch.linalg.pinv(sd["transformer.project_in.weight"].double()).float()
+        sd["transformer.project_out.weight"] = (
+            sd["transformer.project_out.weight"] - skip_gain * (M @ pinv))
     return sd

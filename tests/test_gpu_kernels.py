@@ -1,0 +1,218 @@
+"""GPU parity: hand-written HIP kernels (through the C-ABI) vs the CPU oracle.
+
+Tolerances (written here, per BASELINE.json north_star): waveforms / latents
+within 1e-3 relative L2 of the fp32 CPU path.  The bf16x3 (split-bf16 MFMA)
+mode is the parity mode and is held to much tighter bounds per kernel; the
+single-pass bf16 mode is checked against a looser, documented bound.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dit as odit
+from oracle import oobleck as ovae
+from oracle import pipeline, sampler
+from oracle.make_golden import tiny_vae_weights
+from tests.util import make_engine, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+X3, BF16 = 2, 1
+TOL = {X3: 2e-5, BF16: 1.5e-2}
+
+
+@pytest.fixture(scope="module")
+def bare():
+    engs = {p: make_engine(precision=p) for p in (X3, BF16)}
+    yield engs
+    for e in engs.values():
+        e.close()
+
+
+@pytest.mark.parametrize("prec", [X3, BF16])
+@pytest.mark.parametrize("shape", [(1, 128, 64, 128), (3, 100, 64, 200), (2, 257, 192, 1024), (1, 33, 1024, 96)])
+def test_igemm_linear(bare, prec, shape):
+    B, L, Cin, N = shape
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn((B, L, Cin), generator=g)
+    w = torch.randn((N, Cin), generator=g) / math.sqrt(Cin)
+    out = bare[prec].test_igemm(a, w)
+    ref = (a.double() @ w.double().t())
+    assert rel_l2(out, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [X3, BF16])
+@pytest.mark.parametrize("dil", [1, 3, 9])
+def test_igemm_dilated_conv(bare, prec, dil):
+    B, L, Cin, N, k = 2, 300, 32, 64, 7
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn((B, L, Cin), generator=g)
+    w = torch.randn((N, Cin, k), generator=g) / math.sqrt(Cin * k)
+    packed = w.permute(0, 2, 1).reshape(N, k * Cin)          # [N][tap*Cin + ci]
+    out = bare[prec].test_igemm(a, packed, taps=k, tap_dil=dil, in_pad=3 * dil)
+    ref = F.conv1d(a.double().transpose(1, 2), w.double(), dilation=dil, padding=3 * dil).transpose(1, 2)
+    assert rel_l2(out, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("stride", [2, 4, 8])
+def test_igemm_strided_conv(bare, stride):
+    B, L, Cin, N = 2, 64 * stride, 32, 64
+    k = 2 * stride
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn((B, L, Cin), generator=g)
+    w = torch.randn((N, Cin, k), generator=g) / math.sqrt(Cin * k)
+    packed = w.permute(0, 2, 1).reshape(N, k * Cin)
+    pad = math.ceil(stride / 2)
+    out = bare[X3].test_igemm(a, packed, taps=k, in_stride=stride, in_pad=pad, rows_per_b=L // stride)
+    ref = F.conv1d(a.double().transpose(1, 2), w.double(), stride=stride, padding=pad).transpose(1, 2)
+    assert rel_l2(out, ref) < TOL[X3]
+
+
+def test_igemm_empty_and_ragged_edges(bare):
+    # M not a multiple of the 128-row tile, N not a multiple of 128, K = one 32-chunk
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn((1, 1, 32), generator=g)
+    w = torch.randn((4, 32), generator=g)
+    out = bare[X3].test_igemm(a, w)
+    assert rel_l2(out, a.double() @ w.double().t()) < TOL[X3]
+
+
+def test_schedule_matches_reference_tables(bare, golden):
+    g = golden("sde_tables")
+    for N in (10, 30):
+        s = bare[X3].ouve_schedule(N, 0.03, 0.5)
+        np.testing.assert_allclose(s["t"].numpy(), g[f"t_{N}"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(s["std"].numpy(), g[f"std_{N}"], rtol=2e-6)
+        np.testing.assert_allclose(s["G"].numpy(), g[f"G_{N}"], rtol=2e-6)
+        np.testing.assert_allclose(s["std_T"], g[f"stdT_{N}"][0], rtol=2e-6)
+        co = sampler.step_coefficients(sampler.OUVE(N=N), torch.from_numpy(g[f"t_{N}"]), 0.5)
+        np.testing.assert_allclose(s["step"].numpy(), co["eps_c"].numpy(), rtol=4e-6)
+        np.testing.assert_allclose(s["gain"].numpy(), co["cn"].numpy(), rtol=4e-6)
+
+
+# ------------------------------------------------------------------ DiT score
+@pytest.mark.parametrize("tag", ["2spk", "3spk"])
+@pytest.mark.parametrize("prec,tol", [(X3, 1e-4), (BF16, 3e-2)])
+def test_dit_tiny_vs_golden(golden, tag, prec, tol):
+    g = golden(f"dit_tiny_{tag}")
+    cfg = odit.DiTConfig(n_src=int(g["n_src"]), embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, int(g["seed"]))
+    eng = make_engine(cfg, sd, precision=prec)
+    out = eng.score(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]), torch.from_numpy(g["mix"]))
+    assert rel_l2(out, torch.from_numpy(g["out"])) < tol
+    eng.close()
+
+
+def test_dit_full_size_vs_oracle():
+    """ditsep.json dimensions (1024 x 24 x 16 heads), Libri2Mix latent shape T=32."""
+    torch.set_num_threads(16)
+    cfg = odit.DiTConfig()
+    sd = odit.random_dit_weights(cfg, 3)
+    g = torch.Generator().manual_seed(4)
+    B, T = 3, 32
+    xt = 4.0 * torch.randn((B, 2, 64, T), generator=g)
+    mix = torch.randn((B, 1, 64, T), generator=g)
+    t = torch.tensor([1.0, 0.5, 0.03])
+    ref = odit.DiTScore(sd, cfg)(xt, t, mix)
+    eng = make_engine(cfg, sd, precision=X3)
+    out = eng.score(xt, t, mix)
+    assert rel_l2(out, ref) < 1e-4
+    eng.close()
+
+
+# ------------------------------------------------------------------ Oobleck VAE
+# The golden VAE vectors use channels=8, below the 32-channel K chunk of the MFMA
+# kernel; the GPU parity cases run the same architecture at channels=32 against the
+# oracle, which is itself pinned to the reference by the channels=8 golden vectors.
+@pytest.mark.parametrize("act", ["elu", "snake"])
+@pytest.mark.parametrize("prec,tol", [(X3, 1e-4), (BF16, 3e-2)])
+def test_decoder_tiny_vs_oracle(act, prec, tol):
+    cfg = ovae.OobleckConfig(channels=32, use_snake=(act == "snake"))
+    sd = tiny_vae_weights(cfg, 21)
+    eng = make_engine(vcfg=cfg, vsd=sd, precision=prec, n_src=2)
+    g = torch.Generator().manual_seed(5)
+    est = torch.randn((2, 2, 64, 3), generator=g)
+    ref = ovae.decode_sources(sd, cfg, est, None, "decoder.")
+    out = eng.decode(est)
+    assert out.shape == ref.shape == (2, 2, 3 * 2048)
+    assert rel_l2(out, ref) < tol
+    # crop to target_dim like LatentDiffSep.decode(est, target_dim)
+    out_c = eng.decode(est, 5000)
+    assert torch.equal(out_c.cpu(), out.cpu()[..., :5000])
+    eng.close()
+
+
+@pytest.mark.parametrize("act", ["elu", "snake"])
+def test_encoder_tiny_vs_oracle(act):
+    cfg = ovae.OobleckConfig(channels=32, use_snake=(act == "snake"))
+    sd = tiny_vae_weights(cfg, 21)
+    eng = make_engine(vcfg=cfg, vsd=sd, precision=X3)
+    g = torch.Generator().manual_seed(6)
+    for L in (4000, 4096):                       # 4096 -> a full extra hop of padding (reference quirk)
+        mix = 0.3 * torch.randn((2, 1, L), generator=g)
+        T = eng.latent_frames(L)
+        assert T == sampler.pad_to_hop(mix, 2048).shape[-1] // 2048
+        vn = torch.randn((2, 64, T), generator=g)
+        ref = ovae.encode_mix(sd, cfg, mix, vn, "encoder.")
+        out = eng.encode(mix, vn)
+        assert out.shape == ref.shape
+        assert rel_l2(out, ref) < 1e-4
+    eng.close()
+
+
+# ------------------------------------------------------------------ sampler
+def test_pc_sampler_tiny_dit_vs_oracle():
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 32, out_gain=0.005)
+    eng = make_engine(cfg, sd, precision=X3)
+    g = torch.Generator().manual_seed(7)
+    y = torch.randn((2, 1, 64, 8), generator=g)
+    for c, dn, N in ((1, True, 6), (0, False, 5), (2, True, 3)):
+        noise = sampler.draw_noise(8, 1 + N * (c + 1), (2, 2, 64, 8))
+        ref, nfe = sampler.pc_sample(odit.DiTScore(sd, cfg), y, noise, sampler.OUVE(N=N), eps=0.03, snr=0.5,
+                                     corrector_steps=c, denoise=dn, n_spkrs=2)
+        out, nfe2 = eng.pc_sample(y, noise, N=N, corrector_steps=c, snr=0.5, t_eps=0.03, denoise=dn)
+        assert nfe == nfe2 == N * (c + 1)
+        assert rel_l2(out, ref) < 1e-4
+    eng.close()
+
+
+def test_device_rng_statistics():
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 32, out_gain=0.0)
+    sd["transformer.project_out.weight"].zero_()            # zero score -> x_T statistics are analytic
+    eng = make_engine(cfg, sd, precision=BF16)
+    y = torch.zeros((8, 1, 64, 32))
+    x, _ = eng.pc_sample(y, None, N=1, corrector_steps=0, denoise=False, seed=123)
+    x2, _ = eng.pc_sample(y, None, N=1, corrector_steps=0, denoise=False, seed=123)
+    x3, _ = eng.pc_sample(y, None, N=1, corrector_steps=0, denoise=False, seed=124)
+    assert torch.equal(x, x2) and not torch.equal(x, x3)
+    s = eng.ouve_schedule(1, 0.03, 0.5)
+    # x1 = x0 (1 + theta dt) + G z with x0 = std_T z0  (y = 0, score = 0)
+    var = (s["std_T"] * (1 + 1.5)) ** 2 + float(s["G"][0]) ** 2
+    assert abs(float(x.mean())) < 0.2
+    assert abs(float(x.var()) / var - 1) < 0.05
+    eng.close()
+
+
+# ------------------------------------------------------------------ end to end
+def test_separate_tiny_vs_oracle():
+    vcfg = ovae.OobleckConfig(channels=32)
+    vsd = tiny_vae_weights(vcfg, 31)
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    eng = make_engine(dcfg, dsd, vcfg, vsd, precision=X3)
+    g = torch.Generator().manual_seed(33)
+    B, L, N = 2, 4000, 4
+    mix = 0.3 * torch.randn((B, 1, L), generator=g)
+    ref = pipeline.separate(odit.DiTScore(dsd, dcfg), vsd, vcfg, mix, sampler.OUVE(N=N), 34, n_spkrs=2,
+                            eps=0.03, snr=0.5, corrector_steps=1, target_dim=L)
+    wav, nfe = eng.separate(mix, vae_noise=ref["vae_noise"], noise=ref["noise"], N=N, corrector_steps=1,
+                            snr=0.5, t_eps=0.03)
+    assert nfe == ref["nfe"] == 8
+    assert wav.shape == (B, 2, L)
+    assert rel_l2(wav, ref["wav"]) < 1e-3          # the north-star tolerance
+    eng.close()
