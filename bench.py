@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: separated utterances/sec on the BASELINE.json C2 workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+A "step" = one pass of the hot path over one batch of synthetic Libri2Mix-shape
+mixtures already resident in HBM as latents: N=30 predictor-corrector sampler
+(1 corrector step, 60 score-network calls, on-device Philox noise) followed by the
+Oobleck decode to waveforms -- the region the reference times
+(src/evaluate_latent.py:273-277).  Mixtures are independent: each rank owns a
+64-mixture shard (weak scaling, BASELINE C3 = 8 x 64) and the only collective is
+one RCCL gather of the separated waveforms to rank 0 per step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ditsep_amd import native, synthetic  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FS, SECONDS, N_STEPS, CORR, SNR, T_EPS = 16000, 4, 30, 1, 0.5, 0.03
+DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN = 0.002, 0.02, 0.08
+
+
+def build_engine(device, precision, dcfg, vcfg, dsd, vsd):
+    eng = native.Engine(device=device, precision=precision, n_src=dcfg.n_src, latent_dim=dcfg.latent_dim,
+                        score_kind=native.SCORE_DIT, dit_embed_dim=dcfg.embed_dim, dit_depth=dcfg.depth,
+                        dit_heads=dcfg.num_heads, vae_channels=vcfg.channels, vae_c_mults=vcfg.c_mults,
+                        vae_strides=vcfg.strides, vae_enc_latent_dim=vcfg.enc_latent_dim,
+                        vae_use_snake=vcfg.use_snake, vae_final_tanh=vcfg.final_tanh)
+    eng.load_state_dict(dsd, prefix="score_model.")
+    eng.load_state_dict(vsd, prefix="vae.")
+    eng.finalize()
+    return eng
+
+
+def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
+    """The CPU restatement of the reference path (oracle/, kind = "port") timed on
+    this host: sampler + decode on `n_mix` mixtures of the same workload."""
+    from oracle import dit as odit
+    from oracle import oobleck as ovae
+    from oracle import sampler as osmp
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    T = (L + (vcfg.hop - L % vcfg.hop)) // vcfg.hop
+    g = torch.Generator().manual_seed(99)
+    y = torch.randn((n_mix, 1, vcfg.latent_dim, T), generator=g)
+    noise = osmp.draw_noise(g, 1 + N_STEPS * (CORR + 1), (n_mix, dcfg.n_src, vcfg.latent_dim, T))
+    score = odit.DiTScore(dsd, dcfg)
+    t0 = time.perf_counter()
+    x, nfe = osmp.pc_sample(score, y, noise, osmp.OUVE(N=N_STEPS), eps=T_EPS, snr=SNR, corrector_steps=CORR,
+                            denoise=True, n_spkrs=dcfg.n_src)
+    wav = ovae.decode_sources(vsd, vcfg, x, L, "decoder.")
+    dt = time.perf_counter() - t0
+    return {"value": n_mix / dt, "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_mix} mixtures of the same C2 workload (N=30, 60 NFE, sampler+decode), "
+                      f"PyTorch-CPU fp32 oracle, {dt:.1f} s"}, y, noise, wav
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="mixtures per GPU")
+    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary-precision measurement")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    dcfg = synthetic.DiTConfig()                       # ditsep.json dims: 1024 x 24 layers x 16 heads
+    vcfg = synthetic.OobleckConfig()                   # oobleck_finetune.json
+    dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=DIT_OUT_GAIN, skip_gain=DIT_SKIP_GAIN)
+    vsd = synthetic.vae_weights(vcfg, 2, dec_in_gain=DEC_IN_GAIN)
+    prec = native.PREC_BF16X3 if args.precision == "bf16x3" else native.PREC_BF16
+    eng = build_engine(local, prec, dcfg, vcfg, dsd, vsd)
+    eng.enable_graphs(not args.no_graphs)
+
+    B, L = args.batch, FS * SECONDS
+    src = synthetic.synthetic_sources(B, dcfg.n_src, L, FS, seed=1234 + 100000 * rank)
+    mix = src.sum(1, keepdim=True).to(dev)
+    y = eng.encode(mix, seed=7 + rank)                 # latents resident in HBM before the timed region
+    torch.cuda.synchronize()
+    gather_buf = None
+    if dist is not None and rank == 0:
+        gather_buf = [torch.empty((B, dcfg.n_src, L), device=dev) for _ in range(world)]
+
+    def step(i, engine=eng):
+        x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
+                                  denoise=True, seed=1000 * rank + i)
+        wav = engine.decode(x, L)
+        if dist is not None:
+            dist.gather(wav, gather_buf, dst=0)
+        return wav, nfe
+
+    def timed(k, w, engine=eng):
+        for i in range(w):
+            step(i, engine)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(w + i, engine)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    elapsed = timed(args.steps, args.warmup)
+    value = world * B * args.steps / elapsed
+
+    # dominant kernel roofline: per-launch HIP events around every implicit-GEMM launch of one step
+    eng.profile_begin()
+    step(10_000)
+    prof = eng.profile_end()
+    ach = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                "kernel": "igemm_kernel<%d>" % prec, "launches_per_step": prof["gemm_launches"],
+                "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
+                "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
+                "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
+
+    out = {
+        "metric": "separated utterances/sec @ N=30, 2-spk 4 s mixtures",
+        "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16x3 (split-bf16 hi/lo MFMA operands, fp32 accumulate)" if prec == 2 else "bf16",
+        "data": "synthetic",
+        "config": {"workload": "C2 Libri2Mix-shape: 2-spk 16 kHz 4 s mixtures, N=30 PC sampler "
+                               "(reverse_diffusion + ald, 1 corrector step, 60 NFE) + Oobleck decode, "
+                               f"batch={B} per GPU",
+                   "score_net": "DiT 1024x24x16 (ditsep.json dims) via (xt,t,mix) adapter",
+                   "vae": "Oobleck decoder 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
+                   "global_batch": world * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
+                   "parallelism": f"dp{world}: batch sharded, one RCCL gather of waveforms per step"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            n_cpu = 2
+            cb, y_c, noise_c, wav_c = cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_cpu)
+            out["cpu_baseline"] = cb
+            # live parity of the native path on the very sample the CPU just computed
+            xg, _ = eng.pc_sample(y_c, noise_c, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
+            wg = eng.decode(xg, L).cpu()
+            out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": float((wg.double() - wav_c.double()).norm()
+                                                                   / wav_c.double().norm()),
+                             "tolerance": 1e-3, "mixtures": n_cpu}
+        if not args.no_alt:
+            alt_prec = native.PREC_BF16 if prec == native.PREC_BF16X3 else native.PREC_BF16X3
+            eng2 = build_engine(local, alt_prec, dcfg, vcfg, dsd, vsd)
+            eng2.enable_graphs(not args.no_graphs)
+            el2 = timed(max(1, args.steps), 3, eng2)
+            noise = torch.randn((1 + N_STEPS * (CORR + 1), 4, dcfg.n_src, 64, int(y.shape[-1])), device=dev)
+            wa = eng.decode(eng.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)
+            wb = eng2.decode(eng2.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)
+            out["alt_precision"] = {
+                "dtype": "bf16" if alt_prec == 1 else "bf16x3",
+                "value": round(B * max(1, args.steps) / el2, 3), "unit": "utt/s",
+                "rel_l2_waveform_between_modes": float((wa.double() - wb.double()).norm() / wa.double().norm())}
+            eng2.close()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,13 @@ struct VaeBlock {
 
 struct Graph {
   hipGraphExec_t exec = nullptr;
+  uint64_t epoch = ~0ull;  // workspace epoch the graph (or its eager warm-up) was built against
+  bool warmed = false;
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  double flops;
 };
 
 }  // namespace
@@ -115,6 +122,70 @@ struct dsn_ctx {
   Packed enc_out;
 
   std::map<std::string, Graph> graphs;
+  hipStream_t own = nullptr;  // capture / replay stream (graphs cannot be captured on the NULL stream)
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::vector<float> tv_host;  // uploaded timestep table signature
+  int tv_B = -1;
+
+  // Run `body(stream)` -- a pure sequence of kernel launches over workspace pointers --
+  // either eagerly or as a cached hipGraph.  The first call with a given key runs
+  // eagerly (it may grow the workspace), the second captures, later ones replay.
+  template <class F>
+  void run_graphed(const std::string& key, hipStream_t st, F&& body) {
+    if (!use_graphs || profiling) {
+      body(st);
+      return;
+    }
+    Graph& g = graphs[key];
+    if (g.exec && g.epoch == ws_epoch) {
+      HIPCHK(hipGraphLaunch(g.exec, st));
+      return;
+    }
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+    if (!g.warmed || g.epoch != ws_epoch) {
+      body(st);
+      g.warmed = true;
+      g.epoch = ws_epoch;
+      return;
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    try {
+      body(st);
+    } catch (...) {
+      (void)hipStreamEndCapture(st, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
+    HIPCHK(hipStreamEndCapture(st, &graph));
+    hipError_t e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) fail(DSN_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    HIPCHK(hipGraphLaunch(g.exec, st));
+  }
+  // stream the engine enqueues on: the caller's in eager mode, its own (ordered after the
+  // caller's by an event) in graph mode
+  hipStream_t enter(hipStream_t caller) {
+    if (!use_graphs || profiling) return caller;
+    if (!own) {
+      HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(ev_in, caller));
+    HIPCHK(hipStreamWaitEvent(own, ev_in, 0));
+    return own;
+  }
+  void leave(hipStream_t caller, hipStream_t used) {
+    if (used == caller) return;
+    HIPCHK(hipEventRecord(ev_out, used));
+    HIPCHK(hipStreamWaitEvent(caller, ev_out, 0));
+  }
 
   // ---------------------------------------------------------------- memory
   void* dmalloc(size_t bytes) {
@@ -413,7 +484,18 @@ struct dsn_ctx {
     d.act_mod = a.mod;
   }
   void run(const GemmDesc& d, hipStream_t st) {
+    ProfRec pr;
+    if (profiling) {
+      HIPCHK(hipEventCreate(&pr.a));
+      HIPCHK(hipEventCreate(&pr.b));
+      pr.flops = 2.0 * (double)d.M * (double)d.N * (double)d.taps * (double)d.Cin;
+      HIPCHK(hipEventRecord(pr.a, st));
+    }
     hipError_t e = igemm_launch(d, P, st);
+    if (profiling) {
+      HIPCHK(hipEventRecord(pr.b, st));
+      prof.push_back(pr);
+    }
     if (e != hipSuccess) fail(DSN_EHIP, "igemm launch failed: %s (M=%d N=%d Cin=%d taps=%d)", hipGetErrorString(e),
                               d.M, d.N, d.Cin, d.taps);
   }
@@ -438,12 +520,10 @@ struct dsn_ctx {
     bf16_t* Op = wsbuf<bf16_t>("dit_Op", Mt * io * P);
     float* SC = wsbuf<float>("sc", Mt * io);
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
-    float* rc = wsbuf<float>("rope_cos", (long)257 * rot);
-    float* rs = wsbuf<float>("rope_sin", (long)257 * rot);
-    if (rope_S != S) {
-      launch_rope_tables(rc, rs, S, rot, st);
-      rope_S = S;
-    }
+    const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
+    float* rc = wsbuf<float>("rope_cos_" + std::to_string(S), (long)S * rot);
+    float* rs = wsbuf<float>("rope_sin_" + std::to_string(S), (long)S * rot);
+    if (new_rope) launch_rope_tables(rc, rs, S, rot, st);
 
     launch_pack_tokens(xt, io, mix, Dl, B, T, U, Up, Mt * din, P, st);
     {  // h0 = U Wpre^T + U
@@ -526,7 +606,6 @@ struct dsn_ctx {
     }
     return SC;
   }
-  int rope_S = -1;
 
   float* score_tokens(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
     if (!finalized) fail(DSN_ESTATE, "weights not finalized");
@@ -575,6 +654,19 @@ struct dsn_ctx {
 
   // ---------------------------------------------------------------- sampler
   // y [B,1,Dl,T]; noise [(1+N(c+1))][B,n,Dl,T]; returns device pointer of the result
+  // vec_t = ones(B) * timesteps[i] for every step, uploaded once per (B, schedule)
+  void upload_timesteps(int B, int N, float t_eps, float snr, hipStream_t st) {
+    const Sched s = schedule(N, t_eps, snr);
+    std::vector<float> ht((size_t)B * N);
+    for (int i = 0; i < N; ++i)
+      for (int b = 0; b < B; ++b) ht[(size_t)i * B + b] = s.t[i];
+    float* tv = wsbuf<float>("pc_t", (long)B * N);
+    if (ht == tv_host && tv_B == B) return;
+    HIPCHK(hipMemcpyAsync(tv, ht.data(), sizeof(float) * ht.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    tv_host = ht;
+    tv_B = B;
+  }
   float* pc_sample(const float* y, const float* noise, int B, int T, int N, int c, float snr, float t_eps,
                    int denoise, hipStream_t st) {
     const int n = cfg.n_src, Dl = cfg.latent_dim;
@@ -583,13 +675,6 @@ struct dsn_ctx {
     float* xm = wsbuf<float>("pc_xm", sz);
     float* tv = wsbuf<float>("pc_t", (long)B * N);
     const Sched s = schedule(N, t_eps, snr);
-    {
-      std::vector<float> ht((size_t)B * N);
-      for (int i = 0; i < N; ++i)
-        for (int b = 0; b < B; ++b) ht[(size_t)i * B + b] = s.t[i];
-      HIPCHK(hipMemcpyAsync(tv, ht.data(), sizeof(float) * ht.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));  // ht is a stack-owned staging buffer
-    }
     const float dt = (float)(1.0 / N);
     const float* z = noise;
     launch_pc_prior(y, z, x, s.stdT, B, n, Dl, T, st);
@@ -828,6 +913,9 @@ void dsn_destroy(dsn_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& g : ctx->graphs)
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+  if (ctx->own) (void)hipStreamDestroy(ctx->own);
+  if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+  if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
   for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& kv : ctx->ws) (void)hipFree(kv.second.first);
@@ -893,16 +981,29 @@ int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t see
                   int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream) {
   return guarded(ctx, [&] {
     if (!y || !x_out || B <= 0 || T <= 0 || N <= 0 || corrector_steps < 0) fail(DSN_EINVAL, "dsn_pc_sample: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    const long sz = (long)B * ctx->cfg.n_src * ctx->cfg.latent_dim * T;
+    hipStream_t caller = (hipStream_t)stream;
+    const int n = ctx->cfg.n_src, Dl = ctx->cfg.latent_dim;
+    const long ysz = (long)B * Dl * T, sz = ysz * n;
     const long draws = 1 + (long)N * (corrector_steps + 1);
-    if (!noise) {
-      float* nz = ctx->wsbuf<float>("pc_noise", sz * draws);
+    // stable workspace copies of the caller's tensors (graph replay needs fixed pointers)
+    float* yb = ctx->wsbuf<float>("pc_y", ysz);
+    float* nz = ctx->wsbuf<float>("pc_noise", sz * draws);
+    ctx->upload_timesteps(B, N, t_eps, snr, caller);
+    hipStream_t st = ctx->enter(caller);
+    HIPCHK(hipMemcpyAsync(yb, y, sizeof(float) * ysz, hipMemcpyDeviceToDevice, st));
+    if (noise)
+      HIPCHK(hipMemcpyAsync(nz, noise, sizeof(float) * sz * draws, hipMemcpyDeviceToDevice, st));
+    else
       launch_randn(nz, sz * draws, seed, 0, st);
-      noise = nz;
-    }
-    float* r = ctx->pc_sample(y, noise, B, T, N, corrector_steps, snr, t_eps, denoise, st);
-    HIPCHK(hipMemcpyAsync(x_out, r, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    char key[160];
+    snprintf(key, sizeof key, "pc:%d:%d:%d:%d:%a:%a:%d", B, T, N, corrector_steps, snr, t_eps, denoise);
+    float* res = nullptr;
+    ctx->run_graphed(key, st, [&](hipStream_t s2) {
+      res = ctx->pc_sample(yb, nz, B, T, N, corrector_steps, snr, t_eps, denoise, s2);
+    });
+    if (!res) res = ctx->wsbuf<float>(denoise ? "pc_xm" : "pc_x", sz);  // replayed graph: same buffers
+    HIPCHK(hipMemcpyAsync(x_out, res, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    ctx->leave(caller, st);
     if (nfe_out) *nfe_out = N * (corrector_steps + 1);
     HIPCHK(hipGetLastError());
   });
@@ -919,14 +1020,23 @@ int dsn_latent_frames(const dsn_ctx* ctx, int L) {
 int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream) {
   return guarded(ctx, [&] {
     if (!est || !wav || B <= 0 || T <= 0) fail(DSN_EINVAL, "dsn_decode: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     const int S = B * ctx->cfg.n_src;
     const long Lfull = (long)ctx->hop() * T;
     const long Lt = target_len > 0 ? target_len : Lfull;
     if (Lt > Lfull) fail(DSN_EINVAL, "target_len %ld > decoded length %ld", Lt, Lfull);
-    float* w = ctx->decode(est, S, T, st);
+    const long esz = (long)S * ctx->cfg.latent_dim * T;
+    float* eb = ctx->wsbuf<float>("dec_est", esz);
+    hipStream_t st = ctx->enter(caller);
+    HIPCHK(hipMemcpyAsync(eb, est, sizeof(float) * esz, hipMemcpyDeviceToDevice, st));
+    char key[64];
+    snprintf(key, sizeof key, "dec:%d:%d", S, T);
+    float* w = nullptr;
+    ctx->run_graphed(key, st, [&](hipStream_t s2) { w = ctx->decode(eb, S, T, s2); });
+    if (!w) w = ctx->wsbuf<float>("dec_wav", (long)S * Lfull);
     HIPCHK(hipMemcpy2DAsync(wav, sizeof(float) * Lt, w, sizeof(float) * Lfull, sizeof(float) * Lt, S,
                             hipMemcpyDeviceToDevice, st));
+    ctx->leave(caller, st);
   });
 }
 
@@ -981,6 +1091,37 @@ int dsn_enable_graphs(dsn_ctx* ctx, int enable) {
 }
 
 int64_t dsn_workspace_bytes(const dsn_ctx* ctx) { return ctx ? ctx->ws_bytes() : 0; }
+
+int dsn_profile_begin(dsn_ctx* ctx) {
+  return guarded(ctx, [&] {
+    for (auto& r : ctx->prof) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    ctx->prof.clear();
+    ctx->profiling = true;
+  });
+}
+
+int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches) {
+  return guarded(ctx, [&] {
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0, fl = 0;
+    for (auto& r : ctx->prof) {
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+      ms += t;
+      fl += r.flops;
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = fl;
+    if (gemm_launches) *gemm_launches = (int64_t)ctx->prof.size();
+    ctx->prof.clear();
+    ctx->profiling = false;
+  });
+}
 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N, int taps,
                    int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream) {

@@ -24,7 +24,7 @@ EXPORTS = [
     "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
-    "dsn_workspace_bytes", "dsn_test_igemm",
+    "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
 ]
 
 
@@ -75,11 +75,11 @@ def load_library() -> C.CDLL:
     lib.dsn_enable_graphs.argtypes = [vp, ci]
     lib.dsn_workspace_bytes.restype = C.c_int64
     lib.dsn_workspace_bytes.argtypes = [vp]
+    lib.dsn_profile_begin.argtypes = [vp]
+    lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("dsn_latent_frames", "dsn_hop_length"):
-            pass
+        getattr(lib, name)      # every symbol include/ditsep_hip.h declares must resolve
     _lib = lib
     return lib
 
@@ -235,6 +235,14 @@ class Engine:
 
     def workspace_bytes(self) -> int:
         return self.lib.dsn_workspace_bytes(self.ctx)
+
+    def profile_begin(self):
+        self._check(self.lib.dsn_profile_begin(self.ctx), "dsn_profile_begin")
+
+    def profile_end(self):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.dsn_profile_end(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)), "dsn_profile_end")
+        return {"gemm_ms": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
 
     def test_igemm(self, a, w, *, taps=1, in_stride=1, tap_dil=1, in_pad=0, rows_per_b=None):
         """a [B,Lin,Cin] channels-last, w [N, taps*Cin] -> [B, rows_per_b, N] (kernel test hook)."""

@@ -114,6 +114,12 @@ int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const f
 /* introspection for benchmarks / tests */
 int dsn_enable_graphs(dsn_ctx* ctx, int enable);          /* hipGraph replay of sample/decode */
 int64_t dsn_workspace_bytes(const dsn_ctx* ctx);
+/* Per-launch HIP-event timing of the dominant (implicit-GEMM MFMA) kernel: between begin and
+ * end every launch is bracketed by events on the launch stream (graphs are bypassed).
+ * Returns summed kernel time, summed ALGORITHMIC flops (2*M*N*K of each contraction, the
+ * 3x split-bf16 passes not counted) and the launch count. */
+int dsn_profile_begin(dsn_ctx* ctx);
+int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches);
 
 /* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
  * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */

@@ -22,48 +22,10 @@ Adapter (SURVEY.md F2 -- the reference has no (xt, t, mix) wiring for its DiT):
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
-
 import torch
 import torch.nn.functional as F
 
-
-@dataclass
-class DiTConfig:
-    n_src: int = 2
-    latent_dim: int = 64
-    embed_dim: int = 1024
-    depth: int = 24
-    num_heads: int = 16
-
-    @property
-    def io_channels(self) -> int:
-        return self.n_src * self.latent_dim
-
-    @property
-    def dim_in(self) -> int:
-        return self.io_channels + self.latent_dim
-
-    @property
-    def dim_heads(self) -> int:
-        return self.embed_dim // self.num_heads
-
-    @property
-    def rot_dim(self) -> int:
-        # RotaryEmbedding(max(dim_heads // 2, 32))   transformer.py:800
-        return max(self.dim_heads // 2, 32)
-
-    def reference_kwargs(self) -> dict:
-        """kwargs for the reference DiffusionTransformer matching this adapter."""
-        return dict(
-            io_channels=self.io_channels,
-            input_concat_dim=self.latent_dim,
-            embed_dim=self.embed_dim,
-            depth=self.depth,
-            num_heads=self.num_heads,
-            transformer_type="continuous_transformer",
-            global_cond_type="prepend",
-        )
+from ditsep_amd.synthetic import DiTConfig, dit_param_shapes, random_dit_weights  # noqa: F401
 
 
 def rope_tables(seq_len: int, rot_dim: int, base: float = 10000.0):
@@ -147,71 +109,3 @@ class DiTScore:
         out = dit_forward(self.sd, self.cfg, xt.reshape(B, n * Dl, T), t,
                           mix.reshape(B, Dl, T), self.matmul)
         return out.reshape(B, n, Dl, T)
-
-
-def dit_param_shapes(cfg: DiTConfig) -> dict:
-    """name -> shape of every tensor dit_forward reads (reference key names)."""
-    D, di, io = cfg.embed_dim, cfg.dim_in, cfg.io_channels
-    s = {
-        "timestep_features.weight": (128, 1),
-        "to_timestep_embed.0.weight": (D, 256), "to_timestep_embed.0.bias": (D,),
-        "to_timestep_embed.2.weight": (D, D), "to_timestep_embed.2.bias": (D,),
-        "preprocess_conv.weight": (di, di, 1),
-        "postprocess_conv.weight": (io, io, 1),
-        "transformer.project_in.weight": (D, di),
-        "transformer.project_out.weight": (io, D),
-    }
-    for i in range(cfg.depth):
-        p = f"transformer.layers.{i}."
-        s[p + "pre_norm.gamma"] = (D,)
-        s[p + "self_attn.to_qkv.weight"] = (3 * D, D)
-        s[p + "self_attn.to_out.weight"] = (D, D)
-        s[p + "ff_norm.gamma"] = (D,)
-        s[p + "ff.ff.0.proj.weight"] = (8 * D, D)
-        s[p + "ff.ff.0.proj.bias"] = (8 * D,)
-        s[p + "ff.ff.2.weight"] = (D, 4 * D)
-        s[p + "ff.ff.2.bias"] = (D,)
-    return s
-
-
-def random_dit_weights(cfg: DiTConfig, seed: int, out_gain: float = 1.0,
-                       skip_gain: float = 0.0) -> dict:
-    """Seeded re-randomisation of EVERY parameter (the reference's default init
-    zeroes to_out / ff-out / pre/post convs, SURVEY.md F5, which would make
-    parity vacuous).  Linear weights ~ N(0, 1/fan_in) so activations stay O(1);
-    norm gains ~ 1 + 0.1 N(0,1); biases ~ 0.1 N(0,1).  `out_gain` scales
-    project_out so the score magnitude suits the sampler dynamics.
-
-    `skip_gain` = kappa > 0 adds, through the network's own linear skip path
-    (project_in -> residual stream -> project_out), the term -kappa (x_s - y):
-    the shape of a trained OU score, so that the synthetic sampler contracts
-    towards the mixture like a trained model does instead of random-walking to
-    |x| ~ 100 (no trained weights exist)."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-    for name, shape in dit_param_shapes(cfg).items():
-        if name == "timestep_features.weight":
-            w = torch.randn(shape, generator=g)
-        elif name.endswith("gamma"):
-            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
-        elif name.endswith("bias"):
-            w = 0.1 * torch.randn(shape, generator=g)
-        elif name in ("preprocess_conv.weight", "postprocess_conv.weight"):
-            w = torch.randn(shape, generator=g) * (0.5 / math.sqrt(shape[1]))
-        else:
-            w = torch.randn(shape, generator=g) / math.sqrt(shape[1])
-            if name.endswith("to_out.weight") or name.endswith("ff.ff.2.weight"):
-                w = w * 0.5
-        if name == "transformer.project_out.weight":
-            w = w * out_gain
-        sd[name] = w
-    if skip_gain:
-        n, Dl = cfg.n_src, cfg.latent_dim
-        M = torch.zeros(cfg.io_channels, cfg.dim_in)
-        M[:, : cfg.io_channels] = torch.eye(cfg.io_channels)
-        for s_ in range(n):
-            M[s_ * Dl:(s_ + 1) * Dl, cfg.io_channels:] = -torch.eye(Dl)
-        pinv = torch.linalg.pinv(sd["transformer.project_in.weight"].double()).float()
-        sd["transformer.project_out.weight"] = (
-            sd["transformer.project_out.weight"] - skip_gain * (M @ pinv))
-    return sd

@@ -114,10 +114,8 @@ def _ref_vae(ns, cfg):
 
 
 def tiny_vae_weights(cfg, seed):
-    sd = {}
-    sd.update(ovae.random_weights(ovae.encoder_param_shapes(cfg, "encoder."), seed))
-    sd.update(ovae.random_weights(ovae.decoder_param_shapes(cfg, "decoder."), seed + 1))
-    return sd
+    from ditsep_amd.synthetic import vae_weights
+    return vae_weights(cfg, seed)
 
 
 def _sub(sd, prefix):

@@ -14,34 +14,13 @@ old-style weight-norm `weight_g` / `weight_v`) of
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-
 import torch
 import torch.nn.functional as F
 
+from ditsep_amd.synthetic import (OobleckConfig, decoder_param_shapes, encoder_param_shapes,  # noqa: F401
+                                  random_weights)
+
 from .sampler import pad_to_hop
-
-
-@dataclass
-class OobleckConfig:
-    """Defaults = src/stable_audio_tools/configs/model_configs/autoencoders/oobleck_finetune.json"""
-
-    io_channels: int = 1
-    channels: int = 128
-    c_mults: tuple = (1, 2, 4, 8, 16)
-    strides: tuple = (2, 4, 4, 8, 8)
-    latent_dim: int = 64          # decoder input / bottleneck output
-    enc_latent_dim: int = 128     # encoder output (mean ++ scale)
-    use_snake: bool = False
-    final_tanh: bool = True
-
-    @property
-    def hop(self) -> int:
-        return int(math.prod(self.strides))
-
-    @property
-    def mults(self):
-        return (1,) + tuple(self.c_mults)
 
 
 def fold_weight_norm(sd: dict, prefix: str) -> torch.Tensor:
@@ -132,88 +111,3 @@ def decode_sources(sd, cfg: OobleckConfig, est: torch.Tensor, target_dim=None, p
     B, n, D, T = est.shape
     wav = decoder_forward(sd, cfg, est.reshape(B * n, D, T), prefix).reshape(B, n, -1)
     return wav if target_dim is None else wav[..., :target_dim]
-
-
-# ---------------------------------------------------------------------------
-# parameter inventory + seeded re-randomisation (reference key names)
-# ---------------------------------------------------------------------------
-
-def _wn(shapes, prefix, w_shape, bias=True, transposed=False):
-    shapes[prefix + "weight_g"] = (w_shape[0],) + (1,) * (len(w_shape) - 1)
-    shapes[prefix + "weight_v"] = tuple(w_shape)
-    if bias:
-        shapes[prefix + "bias"] = (w_shape[1] if transposed else w_shape[0],)
-
-
-def _act_shapes(shapes, prefix, ch, snake):
-    if snake:
-        shapes[prefix + "alpha"] = (ch,)
-        shapes[prefix + "beta"] = (ch,)
-
-
-def _ru_shapes(shapes, prefix, ch, snake):
-    _act_shapes(shapes, prefix + "layers.0.", ch, snake)
-    _wn(shapes, prefix + "layers.1.", (ch, ch, 7))
-    _act_shapes(shapes, prefix + "layers.2.", ch, snake)
-    _wn(shapes, prefix + "layers.3.", (ch, ch, 1))
-
-
-def decoder_param_shapes(cfg: OobleckConfig, prefix: str = "") -> dict:
-    m, ch, snake = cfg.mults, cfg.channels, cfg.use_snake
-    s = {}
-    _wn(s, prefix + "layers.0.", (m[-1] * ch, cfg.latent_dim, 7))
-    li = 1
-    for i in range(len(m) - 1, 0, -1):
-        p = f"{prefix}layers.{li}."
-        cin, cout, st = m[i] * ch, m[i - 1] * ch, cfg.strides[i - 1]
-        _act_shapes(s, p + "layers.0.", cin, snake)
-        _wn(s, p + "layers.1.", (cin, cout, 2 * st), transposed=True)
-        for j in range(3):
-            _ru_shapes(s, f"{p}layers.{2 + j}.", cout, snake)
-        li += 1
-    _act_shapes(s, f"{prefix}layers.{li}.", m[0] * ch, snake)
-    _wn(s, f"{prefix}layers.{li + 1}.", (cfg.io_channels, m[0] * ch, 7), bias=False)
-    return s
-
-
-def encoder_param_shapes(cfg: OobleckConfig, prefix: str = "") -> dict:
-    m, ch, snake = cfg.mults, cfg.channels, cfg.use_snake
-    s = {}
-    _wn(s, prefix + "layers.0.", (m[0] * ch, cfg.io_channels, 7))
-    li = 1
-    for i in range(len(m) - 1):
-        p = f"{prefix}layers.{li}."
-        cin, cout, st = m[i] * ch, m[i + 1] * ch, cfg.strides[i]
-        for j in range(3):
-            _ru_shapes(s, f"{p}layers.{j}.", cin, snake)
-        _act_shapes(s, p + "layers.3.", cin, snake)
-        _wn(s, p + "layers.4.", (cout, cin, 2 * st))
-        li += 1
-    _act_shapes(s, f"{prefix}layers.{li}.", m[-1] * ch, snake)
-    _wn(s, f"{prefix}layers.{li + 1}.", (cfg.enc_latent_dim, m[-1] * ch, 3))
-    return s
-
-
-def random_weights(shapes: dict, seed: int, res_gain: float = 0.3) -> dict:
-    """Seeded fill for weight-normed conv stacks: v ~ N(0,1); g chosen so the
-    folded weight has per-output-row norm ~ sqrt(2*fan_out_ratio) keeping
-    activations O(1); biases ~ 0.1 N; snake alpha/beta ~ 0.3 N (log scale)."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-    for name, shape in shapes.items():
-        if name.endswith("weight_v"):
-            sd[name] = torch.randn(shape, generator=g)
-        elif name.endswith("weight_g"):
-            sd[name] = 0.9 + 0.2 * torch.rand(shape, generator=g)
-        elif name.endswith("bias"):
-            sd[name] = 0.1 * torch.randn(shape, generator=g)
-        else:  # alpha / beta
-            sd[name] = 0.3 * torch.randn(shape, generator=g)
-    # folded row norm == g, so a conv maps unit-variance input to ~g^2 variance:
-    # keep g ~ 0.9..1.1, and damp the residual-branch output convs (k=1) by
-    # `res_gain` so 15 stacked residual units keep activations O(1) (Snake is
-    # identity + bounded, it does not shrink variance the way ELU does).
-    for name in list(sd):
-        if name.endswith("layers.3.weight_g") and sd[name].ndim == 3:
-            sd[name] = sd[name] * res_gain
-    return sd

@@ -15,31 +15,10 @@ import math
 
 import torch
 
+from ditsep_amd.synthetic import synthetic_sources  # noqa: F401
+
 from . import oobleck, sampler
 from .sampler import OUVE
-
-
-def synthetic_sources(B: int, n: int, L: int, fs: int = 16000, seed: int = 1234) -> torch.Tensor:
-    """[B, n, L] seeded band-limited noise bursts, peak 0.3.
-    Low-pass: 4 cascaded one-pole sections at 0.4*fs/2-ish, then a 3-8 Hz
-    raised-cosine envelope."""
-    out = torch.empty(B, n, L)
-    tt = torch.arange(L, dtype=torch.float64) / fs
-    for b in range(B):
-        for k in range(n):
-            g = torch.Generator().manual_seed(seed + 1000 * b + k)
-            w = torch.randn(L, generator=g, dtype=torch.float64)
-            # cheap zero-phase low-pass via FFT brick wall at 0.4 * fs
-            spec = torch.fft.rfft(w)
-            freqs = torch.fft.rfftfreq(L, 1.0 / fs)
-            spec = spec * (1.0 / (1.0 + (freqs / (0.4 * fs)) ** 8))
-            w = torch.fft.irfft(spec, n=L)
-            rate = 3.0 + 5.0 * torch.rand(1, generator=g, dtype=torch.float64)
-            phase = 2 * math.pi * torch.rand(1, generator=g, dtype=torch.float64)
-            env = 0.5 * (1 - torch.cos(2 * math.pi * rate * tt + phase))
-            s = w * env
-            out[b, k] = (0.3 * s / s.abs().max()).float()
-    return out
 
 
 def separate(score_fn, vae_sd, vae_cfg: oobleck.OobleckConfig, mix: torch.Tensor, sde: OUVE,
