@@ -28,6 +28,10 @@ if ROOT not in sys.path:
 
 from ditsep_amd import native, synthetic  # noqa: E402
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FS, SECONDS, N_STEPS, CORR, SNR, T_EPS = 16000, 4, 30, 1, 0.5, 0.03
 DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN = 0.002, 0.02, 0.08
@@ -52,7 +56,7 @@ def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
     from oracle import oobleck as ovae
     from oracle import sampler as osmp
 
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DITSEP_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     T = (L + (vcfg.hop - L % vcfg.hop)) // vcfg.hop
     g = torch.Generator().manual_seed(99)
@@ -98,14 +102,17 @@ def main():
     dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=DIT_OUT_GAIN, skip_gain=DIT_SKIP_GAIN)
     vsd = synthetic.vae_weights(vcfg, 2, dec_in_gain=DEC_IN_GAIN)
     prec = native.PREC_BF16X3 if args.precision == "bf16x3" else native.PREC_BF16
+    log("weights generated")
     eng = build_engine(local, prec, dcfg, vcfg, dsd, vsd)
     eng.enable_graphs(not args.no_graphs)
+    log("engine ready")
 
     B, L = args.batch, FS * SECONDS
     src = synthetic.synthetic_sources(B, dcfg.n_src, L, FS, seed=1234 + 100000 * rank)
     mix = src.sum(1, keepdim=True).to(dev)
     y = eng.encode(mix, seed=7 + rank)                 # latents resident in HBM before the timed region
     torch.cuda.synchronize()
+    log("latents encoded", tuple(y.shape))
     gather_buf = None
     if dist is not None and rank == 0:
         gather_buf = [torch.empty((B, dcfg.n_src, L), device=dev) for _ in range(world)]
@@ -141,6 +148,7 @@ def main():
 
     elapsed = timed(args.steps, args.warmup)
     value = world * B * args.steps / elapsed
+    log(f"timed region: {elapsed:.3f} s for {args.steps} steps -> {value:.2f} utt/s")
 
     # dominant kernel roofline: per-launch HIP events around every implicit-GEMM launch of one step
     eng.profile_begin()
@@ -174,7 +182,9 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             n_cpu = 2
+            log("cpu baseline (oracle) ...")
             cb, y_c, noise_c, wav_c = cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_cpu)
+            log("cpu baseline done:", cb["value"], "utt/s on", cb["cores"], "threads")
             out["cpu_baseline"] = cb
             # live parity of the native path on the very sample the CPU just computed
             xg, _ = eng.pc_sample(y_c, noise_c, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
@@ -184,6 +194,7 @@ def main():
                              "tolerance": 1e-3, "mixtures": n_cpu}
         if not args.no_alt:
             alt_prec = native.PREC_BF16 if prec == native.PREC_BF16X3 else native.PREC_BF16X3
+            log("secondary precision ...")
             eng2 = build_engine(local, alt_prec, dcfg, vcfg, dsd, vsd)
             eng2.enable_graphs(not args.no_graphs)
             el2 = timed(max(1, args.steps), 3, eng2)
