@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -483,6 +484,15 @@ struct dsn_ctx {
     d.act_b = a.ib;
     d.act_mod = a.mod;
   }
+  // split-K factor for a GEMM whose output tile count cannot fill the chip (see dit_forward)
+  int pick_ksplit(const GemmDesc& d) const {
+    static const char* env = getenv("DSN_KSPLIT");
+    const int nkt = d.taps * (d.Cin / 32);
+    const int tiles = cdiv(d.M, 128) * cdiv(d.N, 128);
+    int k = env ? atoi(env) : (400 + tiles / 2) / tiles;
+    k = std::min(k, std::min(8, nkt / 8));
+    return std::max(k, 1);
+  }
   void run(const GemmDesc& d, hipStream_t st) {
     ProfRec pr;
     if (profiling) {
@@ -491,7 +501,8 @@ struct dsn_ctx {
       pr.flops = 2.0 * (double)d.M * (double)d.N * (double)d.taps * (double)d.Cin;
       HIPCHK(hipEventRecord(pr.a, st));
     }
-    hipError_t e = igemm_launch(d, P, st);
+    static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
+    hipError_t e = (use_v1 && d.ksplit <= 1) ? igemm_launch(d, P, st) : igemm2_launch(d, P, st);
     if (profiling) {
       HIPCHK(hipEventRecord(pr.b, st));
       prof.push_back(pr);
@@ -555,9 +566,17 @@ struct dsn_ctx {
       e.out_limit = (long)S * D;
       run(e, st);
     }
+    // Residual-stream GEMMs (out-proj, FF-out) have N = D only: at M ~ 2k rows that is too few
+    // 128x128 tiles to fill 256 CUs, so they run split-K into fp32 slabs and the slab reduction
+    // (+ bias + residual) is fused into the LayerNorm that follows.
+    float* slabs = nullptr;
+    int pend_n = 0;
+    const float* pend_bias = nullptr;
+    const long slab_stride = M * D;
     for (int i = 0; i < cfg.dit_depth; ++i) {
       const DitLayer& L = layers[i];
-      launch_layernorm_planes(X, L.g1, L.be1, Ap, M * D, P, (int)M, D, 1e-5f, st);
+      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, P, (int)M, D, 1e-5f, 1,
+                           st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
         d.out_f32 = QKV;
@@ -566,11 +585,22 @@ struct dsn_ctx {
       launch_attention(QKV, rc, rs, rot, Ap, M * D, P, B, S, H, 64, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
-        d.resid = X;
-        d.out_f32 = X;
+        d.ksplit = pick_ksplit(d);
+        if (d.ksplit > 1) {
+          slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
+          d.out_f32 = slabs;
+          d.slab_stride = slab_stride;
+          d.bias = nullptr;
+        } else {
+          d.resid = X;
+          d.out_f32 = X;
+        }
         run(d, st);
+        pend_n = d.ksplit > 1 ? d.ksplit : 0;
+        pend_bias = nullptr;
       }
-      launch_layernorm_planes(X, L.g2, L.be2, Ap, M * D, P, (int)M, D, 1e-5f, st);
+      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, P, (int)M, D, 1e-5f, 1,
+                           st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
         d.swiglu = 1;
@@ -583,12 +613,25 @@ struct dsn_ctx {
       }
       {
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
-        d.resid = X;
-        d.out_f32 = X;
+        d.ksplit = pick_ksplit(d);
+        if (d.ksplit > 1) {
+          slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
+          d.out_f32 = slabs;
+          d.slab_stride = slab_stride;
+          pend_bias = d.bias;
+          d.bias = nullptr;
+        } else {
+          d.resid = X;
+          d.out_f32 = X;
+          pend_bias = nullptr;
+        }
         run(d, st);
+        pend_n = d.ksplit > 1 ? d.ksplit : 0;
       }
     }
-    launch_to_planes(X, Ap, M * D, P, M * D, st);
+    // final residual update + planes of X (no norm before project_out)
+    launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, P, (int)M, D, 1e-5f, 0,
+                         st);
     {  // o = X[b, 1+t] Wout^T
       GemmDesc d = base_desc(Ap, M * D, pout, B, T, S);
       d.in_pad = -1;
@@ -1147,6 +1190,57 @@ int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int
     d.out_f32 = out;
     ctx->run(d, st);
     HIPCHK(hipGetLastError());
+  });
+}
+
+// Development hook: time `iters` back-to-back launches of the implicit-GEMM kernel on random operands.
+int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int tap_dil, int in_pad, int ksplit,
+                    int variant, int iters, double* ms_out) {
+  return guarded(ctx, [&] {
+    const int P = ctx->P;
+    const long an = (long)B * Lin * Cin, wn = (long)N * taps * Cin, on = (long)B * Lin * N;
+    float* af = ctx->wsbuf<float>("b_af", an);
+    float* wf = ctx->wsbuf<float>("b_wf", wn);
+    bf16_t* ap = ctx->wsbuf<bf16_t>("b_a", an * P);
+    bf16_t* wp = ctx->wsbuf<bf16_t>("b_w", wn * P);
+    float* out = ctx->wsbuf<float>("b_o", on * (ksplit > 1 ? ksplit : 1));
+    launch_randn(af, an, 1, 0, nullptr);
+    launch_randn(wf, wn, 2, 0, nullptr);
+    launch_to_planes(af, ap, an, P, an, nullptr);
+    launch_to_planes(wf, wp, wn, P, wn, nullptr);
+    Packed pk;
+    pk.w = wp;
+    pk.ps = wn;
+    pk.N = N;
+    pk.Cin = Cin;
+    pk.taps = taps;
+    pk.K = taps * Cin;
+    GemmDesc d = ctx->base_desc(ap, an, pk, B, Lin, Lin);
+    d.tap_dil = tap_dil;
+    d.in_pad = in_pad;
+    d.out_f32 = out;
+    d.ksplit = ksplit;
+    d.slab_stride = on;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto launch = [&] {
+      hipError_t e = variant == 1 ? igemm_launch(d, P, nullptr)
+                                  : igemm2_launch_cfg(d, P, (variant >> 8) & 0xfff, (variant >> 20) & 0xfff,
+                                                      variant & 0xff, nullptr);
+      if (e != hipSuccess) fail(DSN_EHIP, "bench launch: %s", hipGetErrorString(e));
+    };
+    launch();
+    launch();
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) launch();
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
   });
 }
 

@@ -41,7 +41,14 @@ struct GemmDesc {
   int act_mod;
   int swiglu;          // packed N holds (value16, gate16) interleaved groups; N_out = N/2
   int tiles_m, tiles_n;
+  // split-K: the k-tiles are divided over `ksplit` workgroups per output tile; slice z writes
+  // its raw fp32 partial sums (no bias / residual / activation) to out_f32 + z*slab_stride.
+  // The consumer (residual_norm kernel) adds bias + residual + slabs.
+  int ksplit;
+  long slab_stride;
 };
 
 // launchers (igemm.hip)
-hipError_t igemm_launch(const GemmDesc& d, int planes, hipStream_t stream);
+hipError_t igemm_launch(const GemmDesc& d, int planes, hipStream_t stream);   // v1: register-staged
+hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream);  // v2: glds ring + split-K, auto tile
+hipError_t igemm2_launch_cfg(const GemmDesc& d, int planes, int bm, int bn, int nstage, hipStream_t stream);

@@ -251,3 +251,332 @@ hipError_t igemm_launch(const GemmDesc& din, int planes, hipStream_t stream) {
     hipLaunchKernelGGL(igemm_kernel<2>, dim3(grid), dim3(256), 0, stream, d);
   return hipGetLastError();
 }
+
+// ============================================================================
+// v2 core: direct-to-LDS staging (global_load_lds_dwordx4) into an NSTAGE ring,
+// NSTAGE-1 k-tiles in flight behind a counted s_waitcnt vmcnt(N) and ONE raw
+// s_barrier per k-tile; workgroup tile BM x BN in {128,256}^2 built from 64x64
+// wave tiles (4 / 8 / 16 waves); optional split-K.
+//
+// glds writes LDS lane-linearly (wave base + lane*16 B): one wave-instruction
+// fills a 16-row x 64-B group of a plane tile, lane l -> row l>>2, chunk slot
+// l&3.  The bank swizzle therefore goes on the SOURCE address (slot c holds global
+// chunk c ^ f(row)) and on the fragment read, never on the destination.  Rows that
+// fall outside the sequence (conv zero padding, M/N tails) read a zero page.
+// ============================================================================
+namespace {
+
+template <int P>
+__device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
+                                              int z) {
+  const int nq = (lane >> 4) * 4;
+  if (d.ksplit > 1) {  // raw partial sums to this slice's slab
+    float* slab = d.out_f32 + (long)z * d.slab_stride;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = mw0 + tm * 16 + (lane & 15);
+      if (m >= d.M) continue;
+      const int b = m / d.rows_per_b;
+      const int j = m - b * d.rows_per_b;
+      const long row_rel = (long)j * d.out_row_elems + d.out_off;
+      const long row_abs = (long)b * d.out_bstride + row_rel;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const long rel = row_rel + n;
+        if (rel < 0 || rel >= d.out_limit) continue;
+        *reinterpret_cast<f32x4*>(slab + row_abs + n) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = mw0 + tm * 16 + (lane & 15);
+    if (m >= d.M) continue;
+    const int b = m / d.rows_per_b;
+    const int j = m - b * d.rows_per_b;
+    const long row_rel = (long)j * d.out_row_elems + d.out_off;
+    const long row_abs = (long)b * d.out_bstride + row_rel;
+    if (!d.swiglu) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const long rel = row_rel + n;
+        if (rel < 0 || rel >= d.out_limit) continue;
+        const long off = row_abs + n;
+        f32x4 v = acc[tn][tm];
+        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
+        v *= d.out_scale;
+        if (d.out_f32) {
+          f32x4 o = v;
+          if (d.f32_op == DSN_F32_TANH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
+          }
+          *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
+        }
+        if (d.out_planes) {
+          f32x4 a = v;
+          if (d.act == DSN_ACT_ELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_elu(v[r]);
+          } else if (d.act == DSN_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_silu(v[r]);
+          } else if (d.act == DSN_ACT_SNAKE) {
+            const int ch = n % d.act_mod;
+            const f32x4 al = *reinterpret_cast<const f32x4*>(d.act_a + ch);
+            const f32x4 ib = *reinterpret_cast<const f32x4*>(d.act_b + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
+          }
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bf16_t h, l;
+            dsn_split(a[r], h, l);
+            hi[r] = h;
+            lo[r] = l;
+          }
+          *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
+          if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+        }
+      }
+    } else {
+      // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int np = nw0 + tp * 32;
+        if (np >= d.N) continue;
+        const int feat = (np >> 1) + nq;
+        const long off = row_abs + feat;
+        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
+        if (d.bias) {
+          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
+          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bf16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l);
+          hi[r] = h;
+          lo[r] = l;
+        }
+        *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+      }
+    }
+  }
+}
+
+template <int P, int TBM, int TBN, int NST>
+__global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,
+                                                                                 const bf16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [NST][plane][A rows | W rows][32]
+  constexpr int WN_ = TBN / 64;
+  constexpr int NWAVES = (TBM / 64) * WN_;
+  constexpr int ROWS = TBM + TBN;             // staged rows per plane per k-tile (A rows then W rows)
+  constexpr int PLANE_ELEMS = ROWS * BK;
+  constexpr int STAGE_ELEMS = P * PLANE_ELEMS;
+  constexpr int GROUPS = ROWS / 16;           // 16-row glds groups per plane
+  constexpr int GPW = GROUPS / NWAVES;        // groups per wave
+  static_assert(GROUPS % NWAVES == 0, "row groups must divide over the waves");
+  constexpr int G = GPW * P;                  // glds wave-instructions per wave per k-tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_, wn = wave - wm * WN_;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int ntiles = d.tiles_m * d.tiles_n;
+  const int z = t / ntiles;
+  const int tile = t - z * ntiles;
+  const int tile_m = tile / d.tiles_n, tile_n = tile - tile_m * d.tiles_n;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  const int Ktot = d.taps * d.Cin;
+  const int kc_per_tap = d.Cin / BK;
+  const int nkt_all = d.taps * kc_per_tap;
+  const int kt_begin = (int)((long)nkt_all * z / d.ksplit);
+  const int kt_end = (int)((long)nkt_all * (z + 1) / d.ksplit);
+  const int nkt = kt_end - kt_begin;
+
+  // ---- loader role: this wave stages row groups [wave*GPW, wave*GPW + GPW) ----
+  // unified row addressing: r = js + tap*dil must lie in [0, lim);
+  // element offset = base + r*row_elems + tap*tap_elems + kc*BK
+  const int rsub = lane >> 2, cpos = lane & 3;
+  const int gchunk = cpos ^ ((-(lane >> 4)) & 3);  // source chunk held by this lane's LDS slot
+  const bf16_t* r_src[GPW];
+  long r_ps[GPW];
+  int r_js[GPW], r_dil[GPW];
+  unsigned r_lim[GPW];
+  long r_rowel[GPW], r_tapel[GPW];
+  bool r_ok[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave * GPW + gi;
+    const bool is_a = g < TBM / 16;
+    const int row = (is_a ? g : g - TBM / 16) * 16 + rsub;
+    const int m = m0 + row;
+    const int b = m / d.rows_per_b;
+    const int j = m - b * d.rows_per_b;
+    const int n = n0 + row;
+    r_ok[gi] = is_a ? (m < d.M) : (n < d.N);
+    r_src[gi] = (is_a ? d.A + (long)b * d.in_bstride : d.W + (long)n * Ktot) + gchunk * 8;
+    r_ps[gi] = is_a ? d.a_ps : d.w_ps;
+    r_js[gi] = is_a ? j * d.in_stride - d.in_pad : 0;
+    r_dil[gi] = is_a ? d.tap_dil : 0;
+    r_lim[gi] = is_a ? (unsigned)d.Lin : 1u;
+    r_rowel[gi] = is_a ? d.Cin : 0;
+    r_tapel[gi] = is_a ? 0 : d.Cin;
+  }
+  const bf16_t* zsrc = zero_page + cpos * 8;
+
+  auto issue = [&](int kt, int stage) {
+    const int tap = kt / kc_per_tap;
+    const int kc = kt - tap * kc_per_tap;
+    bf16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * 16 * BK;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int r = r_js[gi] + tap * r_dil[gi];
+      const bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
+      const bf16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * BK;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const bf16_t* g = ok ? g0 + p * r_ps[gi] : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + gi * 16 * BK),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int fsw = swz(frow, fchunk) * 8;
+  const int a_frag_off = (wm * 64 + frow) * BK + fsw;
+  const int w_frag_off = (TBM + wn * 64 + frow) * BK + fsw;
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nkt) issue(kt_begin + s, s);
+
+  for (int i = 0; i < nkt; ++i) {
+    // tile i has landed once at most the loads of the NST-2 younger tiles are outstanding
+    const int younger = min(NST - 2, nkt - 1 - i);
+    if (NST >= 4 && younger >= 2)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+    else if (NST >= 3 && younger >= 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's part of tile i landed; everyone finished tile i-1
+    if (i + NST - 1 < nkt) issue(kt_begin + i + NST - 1, (i + NST - 1) % NST);
+
+    const bf16_t* base = lds + (i % NST) * STAGE_ELEMS;
+    bf16x8 fa[P][4], fw[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fa[p][k] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_ELEMS + a_frag_off + k * 16 * BK);
+        fw[p][k] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_ELEMS + w_frag_off + k * 16 * BK);
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        if (P == 2) {
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P - 1][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[P - 1][tm], acc[tn][tm], 0, 0, 0);
+        }
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+      }
+    }
+  }
+  epilogue_tile<P>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+}
+
+const bf16_t* zero_page() {
+  static bf16_t* zp = nullptr;
+  if (!zp) {
+    if (hipMalloc((void**)&zp, 4096) != hipSuccess) return nullptr;
+    (void)hipMemset(zp, 0, 4096);
+  }
+  return zp;
+}
+
+template <int P, int TBM, int TBN, int NST>
+hipError_t launch_cfg(GemmDesc d, const bf16_t* zp, hipStream_t stream) {
+  d.tiles_m = cdiv(d.M, TBM);
+  d.tiles_n = cdiv(d.N, TBN);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, TBM, TBN, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int grid = d.tiles_m * d.tiles_n * d.ksplit;
+  const size_t smem = (size_t)NST * P * (TBM + TBN) * BK * sizeof(bf16_t);
+  hipLaunchKernelGGL((igemm2_kernel<P, TBM, TBN, NST>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
+                     d, zp);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// cfg: 0 = auto; otherwise BM/128 + 2*(BN/128) + 4*stages packed as  (bm_code | bn_code<<4 | nst<<8)
+hipError_t igemm2_launch_cfg(const GemmDesc& din, int planes, int bm, int bn, int nst, hipStream_t stream) {
+  GemmDesc d = din;
+  if (d.ksplit < 1) d.ksplit = 1;
+  if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
+  if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
+  if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
+  const bf16_t* zp = zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+#define CFG(P_, BM_, BN_, NS_) \
+  if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_) return launch_cfg<P_, BM_, BN_, NS_>(d, zp, stream);
+  CFG(2, 128, 128, 2) CFG(2, 128, 128, 3) CFG(2, 256, 128, 2) CFG(2, 128, 256, 2) CFG(2, 256, 256, 2)
+  CFG(2, 256, 128, 3) CFG(2, 128, 256, 3)
+  CFG(1, 128, 128, 3) CFG(1, 128, 128, 4) CFG(1, 256, 128, 3) CFG(1, 128, 256, 3) CFG(1, 256, 256, 2)
+  CFG(1, 256, 256, 3) CFG(1, 256, 128, 4) CFG(1, 128, 256, 4)
+#undef CFG
+  return hipErrorInvalidValue;
+}
+
+hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream) {
+  // Tile choice from the measured sweep (scripts/gemm_bench.py, profiles/): the kernel is
+  // L2->LDS bandwidth bound, so take the biggest tile whose grid still fills 256 CUs.
+  //   large-M convs:  256x256 (N >= 256) -- 16 waves, operand bytes per flop halved
+  //   N == 128 tails: 128x128 (split-bf16) / 256x128 (bf16)
+  //   ConvTranspose phase GEMMs (M ~ 4k, N = s*Cout >= 4k): 256x128, 3 stages
+  //   DiT regime (M ~ 2k): 128x128; split-K chosen by the caller
+  // Very short K (1x1 convs, K <= 256) is epilogue/HBM bound: the register-staged core wins.
+  int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3;
+  if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, planes, stream);
+  if (d.M >= 8192) {
+    if (d.N >= 256) {
+      bm = bn = 256;
+    } else if (planes == 1) {
+      bm = 256;
+    }
+  } else if (d.M >= 4096 && d.N >= 4096) {
+    bm = 256;
+    nst = 3;
+  }
+  return igemm2_launch_cfg(d, planes, bm, bn, nst, stream);
+}

@@ -25,6 +25,11 @@ void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* s
 // LayerNorm over the last dim (bias optional), fp32 in -> operand planes out
 void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, bf16_t* out, long ps,
                              int planes, int rows, int D, float eps, hipStream_t s);
+// x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a
+// plain copy to operand planes.  D <= 4096, D % 4 == 0.
+void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
+                          const float* gamma, const float* beta, bf16_t* out, long ps, int planes, int rows, int D,
+                          float eps, int do_norm, hipStream_t s);
 // FourierFeatures: t[B], w[half] -> planes [B][2*half] = [cos(2 pi t w), sin(2 pi t w)]
 void launch_timestep_features(const float* t, const float* w, int B, int half, bf16_t* out, long ps,
                               int planes, hipStream_t s);

@@ -166,6 +166,80 @@ __global__ void layernorm_planes_kernel(const float* __restrict__ x, const float
   }
 }
 
+// Residual-stream update fused with the next LayerNorm: x[row] += bias + sum of the split-K
+// partial slabs of the preceding GEMM (written back when any were added), then LayerNorm
+// (or a plain copy) to operand planes.  One wave per row, the row lives in registers.
+template <int MAXV>
+__global__ void residual_norm_kernel(float* __restrict__ x, const float* __restrict__ slabs, int nslab,
+                                     long slab_stride, const float* __restrict__ bias,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     bf16_t* __restrict__ out, long ps, int planes, int rows, int D, float eps,
+                                     int do_norm) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int nv = D >> 2;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+    const long rbase = (long)row * D;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) {
+        f32x4 a = reinterpret_cast<const f32x4*>(x + rbase)[i];
+        if (nslab > 0) {
+          if (bias) a += reinterpret_cast<const f32x4*>(bias)[i];
+          for (int z = 0; z < nslab; ++z) a += reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
+          reinterpret_cast<f32x4*>(x + rbase)[i] = a;
+        }
+        v[k] = a;
+        s += (a[0] + a[1]) + (a[2] + a[3]);
+      }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (do_norm) {
+      mean = wave_sum(s) / D;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int i = lane + k * 64;
+        if (i < nv) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dlt = v[k][r] - mean;
+            q += dlt * dlt;
+          }
+        }
+      }
+      rstd = rsqrtf(wave_sum(q) / D + eps);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) {
+        f32x4 o = v[k];
+        if (do_norm) {
+          const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * g[r];
+          if (beta) o += reinterpret_cast<const f32x4*>(beta)[i];
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bf16_t h, l;
+          dsn_split(o[r], h, l);
+          hi[r] = h;
+          lo[r] = l;
+        }
+        const long oi = (rbase >> 2) + i;
+        reinterpret_cast<bf16x4*>(out)[oi] = hi;
+        if (planes == 2) reinterpret_cast<bf16x4*>(out + ps)[oi] = lo;
+      }
+    }
+  }
+}
+
 __global__ void timestep_features_kernel(const float* __restrict__ t, const float* __restrict__ w, int B, int half,
                                          bf16_t* __restrict__ out, long ps, int planes) {
   const int n = B * half;
@@ -508,6 +582,16 @@ void launch_layernorm_planes(const float* x, const float* gamma, const float* be
                              int planes, int rows, int D, float eps, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_planes_kernel, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, gamma, beta, out, ps,
                      planes, rows, D, eps);
+}
+void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
+                          const float* gamma, const float* beta, bf16_t* out, long ps, int planes, int rows, int D,
+                          float eps, int do_norm, hipStream_t st) {
+  if (D <= 1024)
+    hipLaunchKernelGGL(residual_norm_kernel<4>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
+                       slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm);
+  else
+    hipLaunchKernelGGL(residual_norm_kernel<16>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
+                       slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm);
 }
 void launch_timestep_features(const float* t, const float* w, int B, int half, bf16_t* out, long ps, int planes,
                               hipStream_t st) {

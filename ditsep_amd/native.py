@@ -25,6 +25,7 @@ EXPORTS = [
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
+    "dsn_bench_igemm",
 ]
 
 
@@ -78,6 +79,7 @@ def load_library() -> C.CDLL:
     lib.dsn_profile_begin.argtypes = [vp]
     lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.dsn_bench_igemm.argtypes = [vp] + [ci] * 10 + [C.POINTER(C.c_double)]
     for name in EXPORTS:
         getattr(lib, name)      # every symbol include/ditsep_hip.h declares must resolve
     _lib = lib
@@ -243,6 +245,12 @@ class Engine:
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.dsn_profile_end(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)), "dsn_profile_end")
         return {"gemm_ms": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
+
+    def bench_igemm(self, B, Lin, Cin, N, taps=1, tap_dil=1, in_pad=0, ksplit=1, variant=2, iters=10):
+        ms = C.c_double()
+        self._check(self.lib.dsn_bench_igemm(self.ctx, B, Lin, Cin, N, taps, tap_dil, in_pad, ksplit, variant,
+                                             iters, C.byref(ms)), "dsn_bench_igemm")
+        return ms.value
 
     def test_igemm(self, a, w, *, taps=1, in_stride=1, tap_dil=1, in_pad=0, rows_per_b=None):
         """a [B,Lin,Cin] channels-last, w [N, taps*Cin] -> [B, rows_per_b, N] (kernel test hook)."""

@@ -126,6 +126,11 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N,
                    int taps, int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream);
 
+/* Development hook: average milliseconds of `iters` launches of the implicit-GEMM kernel on random
+ * operands of the given contraction (variant 1 = register-staged core, 2 = glds-ring core). */
+int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int tap_dil, int in_pad, int ksplit,
+                    int variant, int iters, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif
