@@ -32,6 +32,10 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+PRECISIONS = {"bf16": (native.PREC_BF16, "bf16 MFMA operands, fp32 accumulate"),
+              "bf16x3": (native.PREC_BF16X3, "split-bf16 (hi,lo) MFMA operands x3, fp32 accumulate"),
+              "fp16": (native.PREC_FP16, "fp16 MFMA operands, fp32 accumulate"),
+              "fp16x3": (native.PREC_FP16X3, "split-fp16 (hi,lo) MFMA operands x3, fp32 accumulate")}
 PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FS, SECONDS, N_STEPS, CORR, SNR, T_EPS = 16000, 4, 30, 1, 0.5, 0.03
 DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN = 0.002, 0.02, 0.08
@@ -79,7 +83,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="mixtures per GPU")
-    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3")
+    ap.add_argument("--precision", choices=list(PRECISIONS), default="fp16")
+    ap.add_argument("--alt", default="bf16x3,bf16", help="comma list of secondary precisions to also measure")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary-precision measurement")
@@ -101,7 +106,7 @@ def main():
     vcfg = synthetic.OobleckConfig()                   # oobleck_finetune.json
     dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=DIT_OUT_GAIN, skip_gain=DIT_SKIP_GAIN)
     vsd = synthetic.vae_weights(vcfg, 2, dec_in_gain=DEC_IN_GAIN)
-    prec = native.PREC_BF16X3 if args.precision == "bf16x3" else native.PREC_BF16
+    prec = PRECISIONS[args.precision][0]
     log("weights generated")
     eng = build_engine(local, prec, dcfg, vcfg, dsd, vsd)
     eng.enable_graphs(not args.no_graphs)
@@ -157,7 +162,7 @@ def main():
     ach = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
-                "kernel": "igemm_kernel<%d>" % prec, "launches_per_step": prof["gemm_launches"],
+                "kernel": "igemm2_kernel (implicit-GEMM MFMA, %s)" % args.precision, "launches_per_step": prof["gemm_launches"],
                 "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
                 "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
                 "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
@@ -167,7 +172,7 @@ def main():
         "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16x3 (split-bf16 hi/lo MFMA operands, fp32 accumulate)" if prec == 2 else "bf16",
+        "dtype": f"{args.precision} ({PRECISIONS[args.precision][1]})",
         "data": "synthetic",
         "config": {"workload": "C2 Libri2Mix-shape: 2-spk 16 kHz 4 s mixtures, N=30 PC sampler "
                                "(reverse_diffusion + ald, 1 corrector step, 60 NFE) + Oobleck decode, "
@@ -193,19 +198,21 @@ def main():
                                                                    / wav_c.double().norm()),
                              "tolerance": 1e-3, "mixtures": n_cpu}
         if not args.no_alt:
-            alt_prec = native.PREC_BF16 if prec == native.PREC_BF16X3 else native.PREC_BF16X3
-            log("secondary precision ...")
-            eng2 = build_engine(local, alt_prec, dcfg, vcfg, dsd, vsd)
-            eng2.enable_graphs(not args.no_graphs)
-            el2 = timed(max(1, args.steps), 3, eng2)
             noise = torch.randn((1 + N_STEPS * (CORR + 1), 4, dcfg.n_src, 64, int(y.shape[-1])), device=dev)
             wa = eng.decode(eng.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)
-            wb = eng2.decode(eng2.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)
-            out["alt_precision"] = {
-                "dtype": "bf16" if alt_prec == 1 else "bf16x3",
-                "value": round(B * max(1, args.steps) / el2, 3), "unit": "utt/s",
-                "rel_l2_waveform_between_modes": float((wa.double() - wb.double()).norm() / wa.double().norm())}
-            eng2.close()
+            out["alt_precision"] = []
+            for name in [a for a in args.alt.split(",") if a and a != args.precision]:
+                log("secondary precision", name, "...")
+                eng2 = build_engine(local, PRECISIONS[name][0], dcfg, vcfg, dsd, vsd)
+                eng2.enable_graphs(not args.no_graphs)
+                el2 = timed(max(1, args.steps), 3, eng2)
+                wb = eng2.decode(eng2.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR,
+                                                t_eps=T_EPS)[0], L)
+                out["alt_precision"].append({
+                    "dtype": name, "value": round(B * max(1, args.steps) / el2, 3), "unit": "utt/s",
+                    "rel_l2_waveform_vs_headline_mode": float((wb.double() - wa.double()).norm()
+                                                              / wa.double().norm())})
+                eng2.close()
     elif rank == 0:
         out["cpu_baseline"] = None
 

@@ -3,9 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16_t;
+// One 16-bit MFMA operand element, stored as raw bits: bf16 or IEEE fp16 depending on the
+// engine's operand format (DSN_FMT_*).
+typedef unsigned short op16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short op16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short op16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define DSN_WAVE 64
@@ -17,7 +21,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // bf16 matrix cores with fp32 accumulation: ~2^-16 relative operand error at
 // 1/3 of the bf16 MFMA rate (gfx950 has no xf32, and f32-input MFMA runs at
 // 1/16 of the bf16 rate).
-// (DSN_PREC_BF16 = 1 plane, DSN_PREC_BF16X3 = 2 planes: include/ditsep_hip.h)
+// Operand format: bf16 (8-bit mantissa, fp32 range) or fp16 (11-bit mantissa: ~8x smaller
+// rounding error than bf16 at the same MFMA rate; the reference trains under fp16 autocast).
+// Kernels receive both packed in one int `pl`: plane count = pl & 3, fp16 flag = pl >> 4.
+#define DSN_PL(planes, f16) ((planes) | ((f16) << 4))
+#define PL_COUNT(pl) ((pl)&3)
+#define PL_F16(pl) ((pl) >> 4)
 
 // activations applied by producer epilogues when writing operand planes
 enum { DSN_ACT_NONE = 0, DSN_ACT_ELU = 1, DSN_ACT_SNAKE = 2, DSN_ACT_SILU = 3 };
@@ -31,9 +40,16 @@ __device__ __forceinline__ float dsn_snake(float v, float alpha, float inv_beta)
   return v + inv_beta * s * s;
 }
 
-__device__ __forceinline__ void dsn_split(float v, bf16_t& hi, bf16_t& lo) {
-  hi = (bf16_t)v;
-  lo = (bf16_t)(v - (float)hi);
+__device__ __forceinline__ op16_t to_op16(float v, int f16) {
+  return f16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ float from_op16(op16_t u, int f16) {
+  return f16 ? (float)__builtin_bit_cast(_Float16, u) : (float)__builtin_bit_cast(__bf16, u);
+}
+// hi = round(v), lo = round(v - hi) in the operand format
+__device__ __forceinline__ void dsn_split(float v, op16_t& hi, op16_t& lo, int f16) {
+  hi = to_op16(v, f16);
+  lo = to_op16(v - from_op16(hi, f16), f16);
 }
 
 // wave-wide reductions (64 lanes)

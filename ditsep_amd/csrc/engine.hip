@@ -51,7 +51,7 @@ struct DevTensor {
 };
 
 struct Packed {  // K-major packed operand planes of one contraction
-  bf16_t* w = nullptr;
+  op16_t* w = nullptr;
   long ps = 0;
   int N = 0, K = 0, Cin = 0, taps = 0;
   float* bias = nullptr;
@@ -99,7 +99,8 @@ struct ProfRec {
 struct dsn_ctx {
   dsn_config cfg;
   std::string err;
-  int P = 2;
+  int P = 2;   // operand planes
+  int PL = 2;  // DSN_PL(P, fp16 flag) as the kernels take it
   bool finalized = false;
   bool use_graphs = false;
   std::map<std::string, DevTensor> raw;
@@ -238,8 +239,8 @@ struct dsn_ctx {
     p.Cin = p.K;
     p.taps = 1;
     p.ps = (long)p.N * p.K;
-    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
-    launch_pack_weight(w.p, nullptr, p.w, p.ps, P, swiglu ? PACK_LINEAR_SWIGLU : PACK_LINEAR, p.N, p.K, p.K, p.N,
+    p.w = (op16_t*)dmalloc(sizeof(op16_t) * p.ps * P);
+    launch_pack_weight(w.p, nullptr, p.w, p.ps, PL, swiglu ? PACK_LINEAR_SWIGLU : PACK_LINEAR, p.N, p.K, p.K, p.N,
                        1, 1, st);
     if (!bname.empty() && has(bname)) {
       const DevTensor& b = get(bname);
@@ -272,8 +273,8 @@ struct dsn_ctx {
     p.taps = kw;
     p.K = Cin * kw;
     p.ps = (long)p.N * p.K;
-    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
-    launch_pack_weight(v.p, scale, p.w, p.ps, P, PACK_CONV, p.N, p.K, Cin, Cout, kw, 1, st);
+    p.w = (op16_t*)dmalloc(sizeof(op16_t) * p.ps * P);
+    launch_pack_weight(v.p, scale, p.w, p.ps, PL, PACK_CONV, p.N, p.K, Cin, Cout, kw, 1, st);
     p.bias = maybe(prefix + "bias");
     p.bias_mod = Cout;
     return p;
@@ -297,8 +298,8 @@ struct dsn_ctx {
     p.taps = 2;
     p.K = 2 * Cin;
     p.ps = (long)p.N * p.K;
-    p.w = (bf16_t*)dmalloc(sizeof(bf16_t) * p.ps * P);
-    launch_pack_weight(v.p, scale, p.w, p.ps, P, PACK_CONVT, p.N, p.K, Cin, Cout, kw, stride, st);
+    p.w = (op16_t*)dmalloc(sizeof(op16_t) * p.ps * P);
+    launch_pack_weight(v.p, scale, p.w, p.ps, PL, PACK_CONVT, p.N, p.K, Cin, Cout, kw, stride, st);
     p.bias = maybe(prefix + "bias");
     p.bias_mod = Cout;
     return p;
@@ -451,7 +452,7 @@ struct dsn_ctx {
 
   // ---------------------------------------------------------------- GEMM helper
   // dense conv-like contraction over channels-last planes
-  GemmDesc base_desc(const bf16_t* A, long a_ps, const Packed& w, int Bn, int rows_per_b, int Lin) {
+  GemmDesc base_desc(const op16_t* A, long a_ps, const Packed& w, int Bn, int rows_per_b, int Lin) {
     GemmDesc d;
     memset(&d, 0, sizeof d);
     d.A = A;
@@ -502,7 +503,7 @@ struct dsn_ctx {
       HIPCHK(hipEventRecord(pr.a, st));
     }
     static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
-    hipError_t e = (use_v1 && d.ksplit <= 1) ? igemm_launch(d, P, st) : igemm2_launch(d, P, st);
+    hipError_t e = (use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st);
     if (profiling) {
       HIPCHK(hipEventRecord(pr.b, st));
       prof.push_back(pr);
@@ -519,16 +520,16 @@ struct dsn_ctx {
     const long Mt = (long)B * T, M = (long)B * S;
     if (S > 256) fail(DSN_EINVAL, "DiT attention kernel supports at most 255 latent frames (got T=%d)", T);
     float* U = wsbuf<float>("dit_U", Mt * din);
-    bf16_t* Up = wsbuf<bf16_t>("dit_Up", Mt * din * P);
-    bf16_t* H0 = wsbuf<bf16_t>("dit_H0", Mt * din * P);
+    op16_t* Up = wsbuf<op16_t>("dit_Up", Mt * din * P);
+    op16_t* H0 = wsbuf<op16_t>("dit_H0", Mt * din * P);
     float* X = wsbuf<float>("dit_X", M * D);
-    bf16_t* Ap = wsbuf<bf16_t>("dit_Ap", M * D * P);
+    op16_t* Ap = wsbuf<op16_t>("dit_Ap", M * D * P);
     float* QKV = wsbuf<float>("dit_QKV", M * 3 * D);
-    bf16_t* FF = wsbuf<bf16_t>("dit_FF", M * 4 * D * P);
-    bf16_t* TF = wsbuf<bf16_t>("dit_TF", (long)B * 256 * P);
-    bf16_t* TE = wsbuf<bf16_t>("dit_TE", (long)B * D * P);
+    op16_t* FF = wsbuf<op16_t>("dit_FF", M * 4 * D * P);
+    op16_t* TF = wsbuf<op16_t>("dit_TF", (long)B * 256 * P);
+    op16_t* TE = wsbuf<op16_t>("dit_TE", (long)B * D * P);
     float* O = wsbuf<float>("dit_O", Mt * io);
-    bf16_t* Op = wsbuf<bf16_t>("dit_Op", Mt * io * P);
+    op16_t* Op = wsbuf<op16_t>("dit_Op", Mt * io * P);
     float* SC = wsbuf<float>("sc", Mt * io);
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
     const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
@@ -536,7 +537,7 @@ struct dsn_ctx {
     float* rs = wsbuf<float>("rope_sin_" + std::to_string(S), (long)S * rot);
     if (new_rope) launch_rope_tables(rc, rs, S, rot, st);
 
-    launch_pack_tokens(xt, io, mix, Dl, B, T, U, Up, Mt * din, P, st);
+    launch_pack_tokens(xt, io, mix, Dl, B, T, U, Up, Mt * din, PL, st);
     {  // h0 = U Wpre^T + U
       GemmDesc d = base_desc(Up, Mt * din, pre, B, T, T);
       d.resid = U;
@@ -553,7 +554,7 @@ struct dsn_ctx {
       run(d, st);
     }
     {  // timestep token -> X[b, 0]
-      launch_timestep_features(t, tf_w, B, 128, TF, (long)B * 256, P, st);
+      launch_timestep_features(t, tf_w, B, 128, TF, (long)B * 256, PL, st);
       GemmDesc d = base_desc(TF, (long)B * 256, t1, B, 1, 1);
       d.out_planes = TE;
       d.out_ps = (long)B * D;
@@ -575,14 +576,14 @@ struct dsn_ctx {
     const long slab_stride = M * D;
     for (int i = 0; i < cfg.dit_depth; ++i) {
       const DitLayer& L = layers[i];
-      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, P, (int)M, D, 1e-5f, 1,
+      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
                            st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
         d.out_f32 = QKV;
         run(d, st);
       }
-      launch_attention(QKV, rc, rs, rot, Ap, M * D, P, B, S, H, 64, st);
+      launch_attention(QKV, rc, rs, rot, Ap, M * D, PL, B, S, H, 64, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         d.ksplit = pick_ksplit(d);
@@ -599,7 +600,7 @@ struct dsn_ctx {
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
       }
-      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, P, (int)M, D, 1e-5f, 1,
+      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
                            st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
@@ -630,7 +631,7 @@ struct dsn_ctx {
       }
     }
     // final residual update + planes of X (no norm before project_out)
-    launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, P, (int)M, D, 1e-5f, 0,
+    launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, PL, (int)M, D, 1e-5f, 0,
                          st);
     {  // o = X[b, 1+t] Wout^T
       GemmDesc d = base_desc(Ap, M * D, pout, B, T, S);
@@ -754,12 +755,12 @@ struct dsn_ctx {
         maxel = std::max(maxel, (long)S * L * b.cout);
       }
     }
-    bf16_t* zp = wsbuf<bf16_t>("dec_z", (long)S * T * Dl * P);
-    bf16_t* pa = wsbuf<bf16_t>("dec_pa", maxel * P);
-    bf16_t* pb = wsbuf<bf16_t>("dec_pb", maxel * P);
-    bf16_t* ph = wsbuf<bf16_t>("dec_ph", maxel * P);
+    op16_t* zp = wsbuf<op16_t>("dec_z", (long)S * T * Dl * P);
+    op16_t* pa = wsbuf<op16_t>("dec_pa", maxel * P);
+    op16_t* pb = wsbuf<op16_t>("dec_pb", maxel * P);
+    op16_t* ph = wsbuf<op16_t>("dec_ph", maxel * P);
     float* xf = wsbuf<float>("dec_x", maxel);
-    launch_pack_tokens(est, Dl, nullptr, 0, S, T, nullptr, zp, (long)S * T * Dl, P, st);
+    launch_pack_tokens(est, Dl, nullptr, 0, S, T, nullptr, zp, (long)S * T * Dl, PL, st);
     long L = T;
     {
       GemmDesc d = base_desc(zp, (long)S * T * Dl, dec_in, S, T, T);
@@ -819,7 +820,7 @@ struct dsn_ctx {
       L = Lo;
     }
     float* wav = wsbuf<float>("dec_wav", (long)S * L);
-    launch_conv_out1(pa, a_ps, P, dec_out_w, wav, S, (int)L, dec_blocks.back().cout, dec_out_taps,
+    launch_conv_out1(pa, a_ps, PL, dec_out_w, wav, S, (int)L, dec_blocks.back().cout, dec_out_taps,
                      cfg.vae_final_tanh, st);
     return wav;
   }
@@ -837,15 +838,15 @@ struct dsn_ctx {
         maxel = std::max(maxel, (long)S * l * b.cout);
       }
     }
-    bf16_t* pa = wsbuf<bf16_t>("enc_pa", maxel * P);
-    bf16_t* ph = wsbuf<bf16_t>("enc_ph", maxel * P);
-    bf16_t* pb = wsbuf<bf16_t>("enc_pb", maxel * P);
+    op16_t* pa = wsbuf<op16_t>("enc_pa", maxel * P);
+    op16_t* ph = wsbuf<op16_t>("enc_ph", maxel * P);
+    op16_t* pb = wsbuf<op16_t>("enc_pb", maxel * P);
     float* xf = wsbuf<float>("enc_x", maxel);
     long l = L;
     long a_ps = (long)S * l * c0;
     {
       const ActP& a = enc_blocks[0].ru[0].act0;
-      launch_conv_in1(wav, enc_in_w, enc_in_b, S, L, c0, 7, xf, pa, a_ps, P, a.kind, a.a, a.ib, st);
+      launch_conv_in1(wav, enc_in_w, enc_in_b, S, L, c0, 7, xf, pa, a_ps, PL, a.kind, a.a, a.ib, st);
     }
     for (size_t bi = 0; bi < enc_blocks.size(); ++bi) {
       const VaeBlock& b = enc_blocks[bi];
@@ -932,8 +933,8 @@ extern "C" {
 dsn_ctx* dsn_create(const dsn_config* cfg) {
   try {
     if (!cfg) fail(DSN_EINVAL, "null config");
-    if (cfg->precision != DSN_PREC_BF16 && cfg->precision != DSN_PREC_BF16X3)
-      fail(DSN_EINVAL, "precision must be DSN_PREC_BF16 or DSN_PREC_BF16X3");
+    if (cfg->precision < DSN_PREC_BF16 || cfg->precision > DSN_PREC_FP16X3)
+      fail(DSN_EINVAL, "precision must be one of DSN_PREC_{BF16,BF16X3,FP16,FP16X3}");
     if (cfg->vae_n_blocks < 0 || cfg->vae_n_blocks > DSN_MAX_VAE_BLOCKS) fail(DSN_EINVAL, "bad vae_n_blocks");
     if (cfg->n_src < 1 || cfg->latent_dim % 32 != 0) fail(DSN_EINVAL, "bad n_src / latent_dim");
     int ndev = 0;
@@ -942,7 +943,8 @@ dsn_ctx* dsn_create(const dsn_config* cfg) {
     HIPCHK(hipSetDevice(cfg->device));
     dsn_ctx* c = new dsn_ctx();
     c->cfg = *cfg;
-    c->P = cfg->precision;
+    c->P = (cfg->precision == DSN_PREC_BF16X3 || cfg->precision == DSN_PREC_FP16X3) ? 2 : 1;
+    c->PL = DSN_PL(c->P, cfg->precision >= DSN_PREC_FP16 ? 1 : 0);
     return c;
   } catch (const std::exception& e) {
     g_create_err = e.what();
@@ -1170,12 +1172,12 @@ int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int
                    int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream) {
   return guarded(ctx, [&] {
     hipStream_t st = (hipStream_t)stream;
-    const int P = ctx->P;
+    const int P = ctx->P, PL = ctx->PL;
     const long an = (long)B * Lin * Cin, wn = (long)N * taps * Cin;
-    bf16_t* ap = ctx->wsbuf<bf16_t>("t_a", an * P);
-    bf16_t* wp = ctx->wsbuf<bf16_t>("t_w", wn * P);
-    launch_to_planes(a, ap, an, P, an, st);
-    launch_to_planes(w, wp, wn, P, wn, st);
+    op16_t* ap = ctx->wsbuf<op16_t>("t_a", an * P);
+    op16_t* wp = ctx->wsbuf<op16_t>("t_w", wn * P);
+    launch_to_planes(a, ap, an, PL, an, st);
+    launch_to_planes(w, wp, wn, PL, wn, st);
     Packed pk;
     pk.w = wp;
     pk.ps = wn;
@@ -1197,17 +1199,17 @@ int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int
 int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int tap_dil, int in_pad, int ksplit,
                     int variant, int iters, double* ms_out) {
   return guarded(ctx, [&] {
-    const int P = ctx->P;
+    const int P = ctx->P, PL = ctx->PL;
     const long an = (long)B * Lin * Cin, wn = (long)N * taps * Cin, on = (long)B * Lin * N;
     float* af = ctx->wsbuf<float>("b_af", an);
     float* wf = ctx->wsbuf<float>("b_wf", wn);
-    bf16_t* ap = ctx->wsbuf<bf16_t>("b_a", an * P);
-    bf16_t* wp = ctx->wsbuf<bf16_t>("b_w", wn * P);
+    op16_t* ap = ctx->wsbuf<op16_t>("b_a", an * P);
+    op16_t* wp = ctx->wsbuf<op16_t>("b_w", wn * P);
     float* out = ctx->wsbuf<float>("b_o", on * (ksplit > 1 ? ksplit : 1));
     launch_randn(af, an, 1, 0, nullptr);
     launch_randn(wf, wn, 2, 0, nullptr);
-    launch_to_planes(af, ap, an, P, an, nullptr);
-    launch_to_planes(wf, wp, wn, P, wn, nullptr);
+    launch_to_planes(af, ap, an, PL, an, nullptr);
+    launch_to_planes(wf, wp, wn, PL, wn, nullptr);
     Packed pk;
     pk.w = wp;
     pk.ps = wn;
@@ -1225,8 +1227,8 @@ int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     auto launch = [&] {
-      hipError_t e = variant == 1 ? igemm_launch(d, P, nullptr)
-                                  : igemm2_launch_cfg(d, P, (variant >> 8) & 0xfff, (variant >> 20) & 0xfff,
+      hipError_t e = variant == 1 ? igemm_launch(d, PL, nullptr)
+                                  : igemm2_launch_cfg(d, PL, (variant >> 8) & 0xfff, (variant >> 20) & 0xfff,
                                                       variant & 0xff, nullptr);
       if (e != hipSuccess) fail(DSN_EHIP, "bench launch: %s", hipGetErrorString(e));
     };

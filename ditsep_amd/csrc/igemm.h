@@ -17,9 +17,9 @@
 #include "common.h"
 
 struct GemmDesc {
-  const bf16_t* A;
+  const op16_t* A;
   long a_ps;  // plane stride of A (elements)
-  const bf16_t* W;
+  const op16_t* W;
   long w_ps;  // plane stride of W
   int M, N, Cin, taps;
   int rows_per_b, Lin, in_stride, tap_dil, in_pad;
@@ -33,7 +33,7 @@ struct GemmDesc {
   float* out_f32;      // or null
   int f32_op;          // DSN_F32_*
   float out_scale;     // applied after bias + residual
-  bf16_t* out_planes;  // or null: act(out) written as P planes
+  op16_t* out_planes;  // or null: act(out) written as P planes
   long out_ps;
   int act;             // DSN_ACT_*
   const float* act_a;  // snake alpha   (exp applied) [act_mod]
@@ -49,6 +49,7 @@ struct GemmDesc {
 };
 
 // launchers (igemm.hip)
-hipError_t igemm_launch(const GemmDesc& d, int planes, hipStream_t stream);   // v1: register-staged
-hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream);  // v2: glds ring + split-K, auto tile
-hipError_t igemm2_launch_cfg(const GemmDesc& d, int planes, int bm, int bn, int nstage, hipStream_t stream);
+hipError_t igemm_launch(const GemmDesc& d, int pl, hipStream_t stream);   // v1: register-staged
+hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream);  // v2: glds ring + split-K, auto tile
+hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, hipStream_t stream);
+// `pl` = DSN_PL(plane count, fp16 flag)

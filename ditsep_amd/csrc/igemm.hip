@@ -25,10 +25,19 @@ constexpr int TILE_ELEMS = 128 * BK;  // one operand plane tile
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
 
-template <int P>
+template <int F16>
+__device__ __forceinline__ f32x4 mfma16(const op16x8& w, const op16x8& a, const f32x4& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0,
+                                                   0);
+}
+
+template <int P, int F16>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
   // [buf][operand A=0/W=1][plane][row*32 + chunk*8]
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * P * TILE_ELEMS];
+  __shared__ __attribute__((aligned(16))) op16_t lds[2 * 2 * P * TILE_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -72,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
     w_base[i] = (long)n * Ktot + kch * 8;
   }
 
-  bf16x8 ra[P][2], rw[P][2];
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  op16x8 ra[P][2], rw[P][2];
+  const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   auto stage_load = [&](int kt) {
     const int tap = kt / kc_per_tap;
@@ -86,19 +95,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
       const long woff = w_base[i] + (long)tap * d.Cin + kc * BK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        ra[p][i] = ok ? *reinterpret_cast<const bf16x8*>(d.A + p * d.a_ps + aoff) : zero8;
-        rw[p][i] = w_ok[i] ? *reinterpret_cast<const bf16x8*>(d.W + p * d.w_ps + woff) : zero8;
+        ra[p][i] = ok ? *reinterpret_cast<const op16x8*>(d.A + p * d.a_ps + aoff) : zero8;
+        rw[p][i] = w_ok[i] ? *reinterpret_cast<const op16x8*>(d.W + p * d.w_ps + woff) : zero8;
       }
     }
   };
   auto stage_store = [&](int buf) {
-    bf16_t* base = lds + buf * (2 * P * TILE_ELEMS);
+    op16_t* base = lds + buf * (2 * P * TILE_ELEMS);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        *reinterpret_cast<bf16x8*>(base + (0 * P + p) * TILE_ELEMS + s_lds[i]) = ra[p][i];
-        *reinterpret_cast<bf16x8*>(base + (1 * P + p) * TILE_ELEMS + s_lds[i]) = rw[p][i];
+        *reinterpret_cast<op16x8*>(base + (0 * P + p) * TILE_ELEMS + s_lds[i]) = ra[p][i];
+        *reinterpret_cast<op16x8*>(base + (1 * P + p) * TILE_ELEMS + s_lds[i]) = rw[p][i];
       }
     }
   };
@@ -123,14 +132,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) stage_load(kt + 1);
 
-    const bf16_t* base = lds + buf * (2 * P * TILE_ELEMS);
-    bf16x8 fa[P][4], fw[P][4];
+    const op16_t* base = lds + buf * (2 * P * TILE_ELEMS);
+    op16x8 fa[P][4], fw[P][4];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[p][i] = *reinterpret_cast<const bf16x8*>(base + (0 * P + p) * TILE_ELEMS + a_frag_off + i * 16 * BK);
-        fw[p][i] = *reinterpret_cast<const bf16x8*>(base + (1 * P + p) * TILE_ELEMS + w_frag_off + i * 16 * BK);
+        fa[p][i] = *reinterpret_cast<const op16x8*>(base + (0 * P + p) * TILE_ELEMS + a_frag_off + i * 16 * BK);
+        fw[p][i] = *reinterpret_cast<const op16x8*>(base + (1 * P + p) * TILE_ELEMS + w_frag_off + i * 16 * BK);
       }
     }
 #pragma unroll
@@ -138,10 +147,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
         if (P == 2) {
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P - 1][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[P - 1][tm], acc[tn][tm], 0, 0, 0);
+          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
         }
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
       }
     }
     if (kt + 1 < nkt) stage_store(buf ^ 1);
@@ -196,16 +205,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
           }
-          bf16x4 hi, lo;
+          op16x4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            bf16_t h, l;
-            dsn_split(a[r], h, l);
+            op16_t h, l;
+            dsn_split(a[r], h, l, F16);
             hi[r] = h;
             lo[r] = l;
           }
-          *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
-          if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+          *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
         }
       }
     } else {
@@ -221,16 +230,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
           val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
           gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
         }
-        bf16x4 hi, lo;
+        op16x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          bf16_t h, l;
-          dsn_split(val[r] * dsn_silu(gate[r]), h, l);
+          op16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
           hi[r] = h;
           lo[r] = l;
         }
-        *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
-        if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
       }
     }
   }
@@ -238,17 +247,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
 
 }  // namespace
 
-hipError_t igemm_launch(const GemmDesc& din, int planes, hipStream_t stream) {
+hipError_t igemm_launch(const GemmDesc& din, int pl, hipStream_t stream) {
+  const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   GemmDesc d = din;
   d.tiles_m = cdiv(d.M, BM);
   d.tiles_n = cdiv(d.N, BN);
   if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   const int grid = d.tiles_m * d.tiles_n;
-  if (planes == 1)
-    hipLaunchKernelGGL(igemm_kernel<1>, dim3(grid), dim3(256), 0, stream, d);
+  if (planes == 1 && !f16)
+    hipLaunchKernelGGL((igemm_kernel<1, 0>), dim3(grid), dim3(256), 0, stream, d);
+  else if (planes == 2 && !f16)
+    hipLaunchKernelGGL((igemm_kernel<2, 0>), dim3(grid), dim3(256), 0, stream, d);
+  else if (planes == 1)
+    hipLaunchKernelGGL((igemm_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, d);
   else
-    hipLaunchKernelGGL(igemm_kernel<2>, dim3(grid), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL((igemm_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, d);
   return hipGetLastError();
 }
 
@@ -266,7 +280,7 @@ hipError_t igemm_launch(const GemmDesc& din, int planes, hipStream_t stream) {
 // ============================================================================
 namespace {
 
-template <int P>
+template <int P, int F16>
 __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
                                               int z) {
   const int nq = (lane >> 4) * 4;
@@ -334,16 +348,16 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
           }
-          bf16x4 hi, lo;
+          op16x4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            bf16_t h, l;
-            dsn_split(a[r], h, l);
+            op16_t h, l;
+            dsn_split(a[r], h, l, F16);
             hi[r] = h;
             lo[r] = l;
           }
-          *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
-          if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+          *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
         }
       }
     } else {
@@ -359,25 +373,25 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
           val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
           gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
         }
-        bf16x4 hi, lo;
+        op16x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          bf16_t h, l;
-          dsn_split(val[r] * dsn_silu(gate[r]), h, l);
+          op16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
           hi[r] = h;
           lo[r] = l;
         }
-        *reinterpret_cast<bf16x4*>(d.out_planes + off) = hi;
-        if (P == 2) *reinterpret_cast<bf16x4*>(d.out_planes + d.out_ps + off) = lo;
+        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
       }
     }
   }
 }
 
-template <int P, int TBM, int TBN, int NST>
+template <int P, int F16, int TBM, int TBN, int NST>
 __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,
-                                                                                 const bf16_t* __restrict__ zero_page) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];  // [NST][plane][A rows | W rows][32]
+                                                                                 const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows][32]
   constexpr int WN_ = TBN / 64;
   constexpr int NWAVES = (TBM / 64) * WN_;
   constexpr int ROWS = TBM + TBN;             // staged rows per plane per k-tile (A rows then W rows)
@@ -414,7 +428,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   // element offset = base + r*row_elems + tap*tap_elems + kc*BK
   const int rsub = lane >> 2, cpos = lane & 3;
   const int gchunk = cpos ^ ((-(lane >> 4)) & 3);  // source chunk held by this lane's LDS slot
-  const bf16_t* r_src[GPW];
+  const op16_t* r_src[GPW];
   long r_ps[GPW];
   int r_js[GPW], r_dil[GPW];
   unsigned r_lim[GPW];
@@ -438,20 +452,20 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     r_rowel[gi] = is_a ? d.Cin : 0;
     r_tapel[gi] = is_a ? 0 : d.Cin;
   }
-  const bf16_t* zsrc = zero_page + cpos * 8;
+  const op16_t* zsrc = zero_page + cpos * 8;
 
   auto issue = [&](int kt, int stage) {
     const int tap = kt / kc_per_tap;
     const int kc = kt - tap * kc_per_tap;
-    bf16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * 16 * BK;
+    op16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * 16 * BK;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int r = r_js[gi] + tap * r_dil[gi];
       const bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
-      const bf16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * BK;
+      const op16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * BK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const bf16_t* g = ok ? g0 + p * r_ps[gi] : zsrc;
+        const op16_t* g = ok ? g0 + p * r_ps[gi] : zsrc;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + gi * 16 * BK),
                                          16, 0, 0);
@@ -486,14 +500,14 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     __builtin_amdgcn_s_barrier();  // everyone's part of tile i landed; everyone finished tile i-1
     if (i + NST - 1 < nkt) issue(kt_begin + i + NST - 1, (i + NST - 1) % NST);
 
-    const bf16_t* base = lds + (i % NST) * STAGE_ELEMS;
-    bf16x8 fa[P][4], fw[P][4];
+    const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
+    op16x8 fa[P][4], fw[P][4];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        fa[p][k] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_ELEMS + a_frag_off + k * 16 * BK);
-        fw[p][k] = *reinterpret_cast<const bf16x8*>(base + p * PLANE_ELEMS + w_frag_off + k * 16 * BK);
+        fa[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_frag_off + k * 16 * BK);
+        fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_frag_off + k * 16 * BK);
       }
     }
 #pragma unroll
@@ -501,18 +515,18 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
         if (P == 2) {
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P - 1][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[P - 1][tm], acc[tn][tm], 0, 0, 0);
+          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
         }
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
+        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
       }
     }
   }
-  epilogue_tile<P>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+  epilogue_tile<P, F16>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
 }
 
-const bf16_t* zero_page() {
-  static bf16_t* zp = nullptr;
+const op16_t* zero_page() {
+  static op16_t* zp = nullptr;
   if (!zp) {
     if (hipMalloc((void**)&zp, 4096) != hipSuccess) return nullptr;
     (void)hipMemset(zp, 0, 4096);
@@ -520,19 +534,19 @@ const bf16_t* zero_page() {
   return zp;
 }
 
-template <int P, int TBM, int TBN, int NST>
-hipError_t launch_cfg(GemmDesc d, const bf16_t* zp, hipStream_t stream) {
+template <int P, int F16, int TBM, int TBN, int NST>
+hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = cdiv(d.M, TBM);
   d.tiles_n = cdiv(d.N, TBN);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, TBM, TBN, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * P * (TBM + TBN) * BK * sizeof(bf16_t);
-  hipLaunchKernelGGL((igemm2_kernel<P, TBM, TBN, NST>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
+  const size_t smem = (size_t)NST * P * (TBM + TBN) * BK * sizeof(op16_t);
+  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
                      d, zp);
   return hipGetLastError();
 }
@@ -540,16 +554,18 @@ hipError_t launch_cfg(GemmDesc d, const bf16_t* zp, hipStream_t stream) {
 }  // namespace
 
 // cfg: 0 = auto; otherwise BM/128 + 2*(BN/128) + 4*stages packed as  (bm_code | bn_code<<4 | nst<<8)
-hipError_t igemm2_launch_cfg(const GemmDesc& din, int planes, int bm, int bn, int nst, hipStream_t stream) {
+hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int nst, hipStream_t stream) {
+  const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
   if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
-  const bf16_t* zp = zero_page();
+  const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define CFG(P_, BM_, BN_, NS_) \
-  if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_) return launch_cfg<P_, BM_, BN_, NS_>(d, zp, stream);
+#define CFG(P_, BM_, BN_, NS_)                                           \
+  if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_)              \
+    return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_>(d, zp, stream) : launch_cfg<P_, 0, BM_, BN_, NS_>(d, zp, stream);
   CFG(2, 128, 128, 2) CFG(2, 128, 128, 3) CFG(2, 256, 128, 2) CFG(2, 128, 256, 2) CFG(2, 256, 256, 2)
   CFG(2, 256, 128, 3) CFG(2, 128, 256, 3)
   CFG(1, 128, 128, 3) CFG(1, 128, 128, 4) CFG(1, 256, 128, 3) CFG(1, 128, 256, 3) CFG(1, 256, 256, 2)
@@ -558,7 +574,8 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int planes, int bm, int bn, in
   return hipErrorInvalidValue;
 }
 
-hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream) {
+hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
+  const int planes = PL_COUNT(pl);
   // Tile choice from the measured sweep (scripts/gemm_bench.py, profiles/): the kernel is
   // L2->LDS bandwidth bound, so take the biggest tile whose grid still fills 256 CUs.
   //   large-M convs:  256x256 (N >= 256) -- 16 waves, operand bytes per flop halved
@@ -567,7 +584,7 @@ hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream) {
   //   DiT regime (M ~ 2k): 128x128; split-K chosen by the caller
   // Very short K (1x1 convs, K <= 256) is epilogue/HBM bound: the register-staged core wins.
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3;
-  if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, planes, stream);
+  if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, pl, stream);
   if (d.M >= 8192) {
     if (d.N >= 256) {
       bm = bn = 256;
@@ -578,5 +595,5 @@ hipError_t igemm2_launch(const GemmDesc& d, int planes, hipStream_t stream) {
     bm = 256;
     nst = 3;
   }
-  return igemm2_launch_cfg(d, planes, bm, bn, nst, stream);
+  return igemm2_launch_cfg(d, pl, bm, bn, nst, stream);
 }

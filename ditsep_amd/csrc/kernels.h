@@ -6,11 +6,11 @@
 // src0 [B][C0][T] (+ src1 [B][C1][T]) channel-major fp32 -> token-major
 // dst[(b*T + t)*(C0+C1) + c] as fp32 (optional) and as operand planes (optional).
 void launch_pack_tokens(const float* src0, int C0, const float* src1, int C1, int B, int T,
-                        float* dst_f32, bf16_t* dst_planes, long ps, int planes, hipStream_t s);
+                        float* dst_f32, op16_t* dst_planes, long ps, int planes, hipStream_t s);
 // token-major fp32 [B*T][C] -> channel-major [B][C][T]
 void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hipStream_t s);
 // fp32 [n] -> operand planes, optional activation
-void launch_to_planes(const float* src, bf16_t* dst, long ps, int planes, long n, hipStream_t s);
+void launch_to_planes(const float* src, op16_t* dst, long ps, int planes, long n, hipStream_t s);
 
 // ---- predictor-corrector sampler (OUVE; reference layout x[B,n,D,T], y[B,1,D,T]) ----
 // score is token-major [B*T][n*D].
@@ -23,30 +23,30 @@ void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* s
 
 // ---- DiT pieces ---------------------------------------------------------------
 // LayerNorm over the last dim (bias optional), fp32 in -> operand planes out
-void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, bf16_t* out, long ps,
+void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, op16_t* out, long ps,
                              int planes, int rows, int D, float eps, hipStream_t s);
 // x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a
 // plain copy to operand planes.  D <= 4096, D % 4 == 0.
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
-                          const float* gamma, const float* beta, bf16_t* out, long ps, int planes, int rows, int D,
+                          const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
                           float eps, int do_norm, hipStream_t s);
 // FourierFeatures: t[B], w[half] -> planes [B][2*half] = [cos(2 pi t w), sin(2 pi t w)]
-void launch_timestep_features(const float* t, const float* w, int B, int half, bf16_t* out, long ps,
+void launch_timestep_features(const float* t, const float* w, int B, int half, op16_t* out, long ps,
                               int planes, hipStream_t s);
 // softmax(q k^T / sqrt(dh)) v with partial rotary embedding applied to q and k.
 // qkv fp32 [B*S][3*H*dh] (q | k | v, head-major inside each), out planes [B*S][H*dh].
 // rope_cos/sin [S][rot] fp32 tables (freqs duplicated over the two halves).
-void launch_attention(const float* qkv, const float* rope_cos, const float* rope_sin, int rot, bf16_t* out,
+void launch_attention(const float* qkv, const float* rope_cos, const float* rope_sin, int rot, op16_t* out,
                       long ps, int planes, int B, int S, int H, int dh, hipStream_t s);
 void launch_rope_tables(float* cos_t, float* sin_t, int S, int rot, hipStream_t s);
 
 // ---- Oobleck edges -------------------------------------------------------------
 // final decoder conv: planes [S*L][C] (already activated), w fp32 [7][C] -> tanh(sum) fp32 [S*L]
-void launch_conv_out1(const bf16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
+void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
                       int ktaps, int apply_tanh, hipStream_t s);
 // first encoder conv: wav fp32 [S][L] (Cin = 1), w [Cout][K], bias -> fp32 x [S*L][Cout] + act planes
 void launch_conv_in1(const float* wav, const float* w, const float* bias, int S, int L, int Cout, int ktaps,
-                     float* out_f32, bf16_t* out_planes, long ps, int planes, int act, const float* act_a,
+                     float* out_f32, op16_t* out_planes, long ps, int planes, int act, const float* act_a,
                      const float* act_b, hipStream_t s);
 // VAE bottleneck sample: enc fp32 token-major [S*T][2*D] (mean | scale) + noise [S][D][T] -> y [S][D][T]
 void launch_vae_sample(const float* enc_tok, const float* noise, float* y, int S, int D, int T, hipStream_t s);
@@ -60,7 +60,7 @@ enum { PACK_LINEAR = 0, PACK_LINEAR_SWIGLU = 1, PACK_CONV = 2, PACK_CONVT = 3 };
 // per-row scale g / ||v|| for old-style weight norm (norm over all dims but 0); v [R][inner]
 void launch_wn_scale(const float* v, const float* g, float* scale, int R, long inner, hipStream_t s);
 // generic gather into packed [N][K] planes; see kernels.hip for the index maps
-void launch_pack_weight(const float* src, const float* scale, bf16_t* dst, long ps, int planes, int mode,
+void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long ps, int planes, int mode,
                         int N, int K, int Cin, int Cout, int kw, int stride, hipStream_t s);
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t s);
 // snake parameters: alpha -> exp(alpha), beta -> 1/(exp(beta)+1e-9)

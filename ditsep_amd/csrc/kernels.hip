@@ -13,16 +13,17 @@ inline int grid_for(long n, int per_block = TPB, int cap = 256 * 16) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-__device__ __forceinline__ void store_planes(bf16_t* dst, long ps, int planes, long i, float v) {
-  bf16_t h, l;
-  dsn_split(v, h, l);
+// `planes` everywhere in this file is the packed DSN_PL(plane count, fp16 flag)
+__device__ __forceinline__ void store_planes(op16_t* dst, long ps, int planes, long i, float v) {
+  op16_t h, l;
+  dsn_split(v, h, l, PL_F16(planes));
   dst[i] = h;
-  if (planes == 2) dst[ps + i] = l;
+  if (PL_COUNT(planes) == 2) dst[ps + i] = l;
 }
 
 // ------------------------------------------------------------------ transforms
 __global__ void pack_tokens_kernel(const float* __restrict__ s0, int C0, const float* __restrict__ s1, int C1,
-                                   int B, int T, float* __restrict__ df, bf16_t* __restrict__ dp, long ps,
+                                   int B, int T, float* __restrict__ df, op16_t* __restrict__ dp, long ps,
                                    int planes) {
   const int C = C0 + C1;
   const long n = (long)B * T * C;
@@ -48,20 +49,20 @@ __global__ void unpack_tokens_kernel(const float* __restrict__ src, float* __res
   }
 }
 
-__global__ void to_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long ps, int planes,
+__global__ void to_planes_kernel(const float* __restrict__ src, op16_t* __restrict__ dst, long ps, int planes,
                                  long n4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    bf16x4 hi, lo;
+    op16x4 hi, lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      bf16_t h, l;
-      dsn_split(v[r], h, l);
+      op16_t h, l;
+      dsn_split(v[r], h, l, PL_F16(planes));
       hi[r] = h;
       lo[r] = l;
     }
-    reinterpret_cast<bf16x4*>(dst)[i] = hi;
-    if (planes == 2) reinterpret_cast<bf16x4*>(dst + ps)[i] = lo;
+    reinterpret_cast<op16x4*>(dst)[i] = hi;
+    if (PL_COUNT(planes) == 2) reinterpret_cast<op16x4*>(dst + ps)[i] = lo;
   }
 }
 
@@ -118,7 +119,7 @@ __global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm
 // one wave per row, float4 per lane per pass
 __global__ void layernorm_planes_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, bf16_t* __restrict__ out, long ps,
+                                        const float* __restrict__ beta, op16_t* __restrict__ out, long ps,
                                         int planes, int rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -151,17 +152,17 @@ __global__ void layernorm_planes_kernel(const float* __restrict__ x, const float
         const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[i];
         o += bb;
       }
-      bf16x4 hi, lo;
+      op16x4 hi, lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bf16_t h, l;
-        dsn_split(o[r], h, l);
+        op16_t h, l;
+        dsn_split(o[r], h, l, PL_F16(planes));
         hi[r] = h;
         lo[r] = l;
       }
       const long oi = ((long)row * D >> 2) + i;
-      reinterpret_cast<bf16x4*>(out)[oi] = hi;
-      if (planes == 2) reinterpret_cast<bf16x4*>(out + ps)[oi] = lo;
+      reinterpret_cast<op16x4*>(out)[oi] = hi;
+      if (PL_COUNT(planes) == 2) reinterpret_cast<op16x4*>(out + ps)[oi] = lo;
     }
   }
 }
@@ -173,7 +174,7 @@ template <int MAXV>
 __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restrict__ slabs, int nslab,
                                      long slab_stride, const float* __restrict__ bias,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     bf16_t* __restrict__ out, long ps, int planes, int rows, int D, float eps,
+                                     op16_t* __restrict__ out, long ps, int planes, int rows, int D, float eps,
                                      int do_norm) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -224,24 +225,24 @@ __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restr
           for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * g[r];
           if (beta) o += reinterpret_cast<const f32x4*>(beta)[i];
         }
-        bf16x4 hi, lo;
+        op16x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          bf16_t h, l;
-          dsn_split(o[r], h, l);
+          op16_t h, l;
+          dsn_split(o[r], h, l, PL_F16(planes));
           hi[r] = h;
           lo[r] = l;
         }
         const long oi = (rbase >> 2) + i;
-        reinterpret_cast<bf16x4*>(out)[oi] = hi;
-        if (planes == 2) reinterpret_cast<bf16x4*>(out + ps)[oi] = lo;
+        reinterpret_cast<op16x4*>(out)[oi] = hi;
+        if (PL_COUNT(planes) == 2) reinterpret_cast<op16x4*>(out + ps)[oi] = lo;
       }
     }
   }
 }
 
 __global__ void timestep_features_kernel(const float* __restrict__ t, const float* __restrict__ w, int B, int half,
-                                         bf16_t* __restrict__ out, long ps, int planes) {
+                                         op16_t* __restrict__ out, long ps, int planes) {
   const int n = B * half;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int b = i / half, k = i - b * half;
@@ -272,7 +273,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
                                                         const float* __restrict__ rcos,
                                                         const float* __restrict__ rsin, int rot,
-                                                        bf16_t* __restrict__ out, long ps, int planes, int S,
+                                                        op16_t* __restrict__ out, long ps, int planes, int S,
                                                         int H) {
   static_assert(DH == 64, "lane = feature mapping assumes 64-wide heads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // Cout == 1 convolution over already-activated planes: 64 outputs per workgroup,
 // (64 + ktaps - 1) rows staged in LDS (fp32, rows padded by 4 floats), 4 channel
 // quarters reduced through LDS.
-__global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict__ a, long ps, int planes,
+__global__ __launch_bounds__(256) void conv_out1_kernel(const op16_t* __restrict__ a, long ps, int planes,
                                                         const float* __restrict__ w, float* __restrict__ out,
                                                         int L, int C, int ktaps, int apply_tanh) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -370,13 +371,13 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict
     float v[8];
     if (l >= 0 && l < L) {
       const long gi = ((long)s * L + l) * C + ch;
-      const bf16x8 hi = *reinterpret_cast<const bf16x8*>(a + gi);
+      const op16x8 hi = *reinterpret_cast<const op16x8*>(a + gi);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (float)hi[k];
-      if (planes == 2) {
-        const bf16x8 lo = *reinterpret_cast<const bf16x8*>(a + ps + gi);
+      for (int k = 0; k < 8; ++k) v[k] = from_op16(hi[k], PL_F16(planes));
+      if (PL_COUNT(planes) == 2) {
+        const op16x8 lo = *reinterpret_cast<const op16x8*>(a + ps + gi);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += (float)lo[k];
+        for (int k = 0; k < 8; ++k) v[k] += from_op16(lo[k], PL_F16(planes));
       }
     } else {
 #pragma unroll
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const bf16_t* __restrict
 
 __global__ void conv_in1_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                 const float* __restrict__ bias, int L, int Cout, int ktaps,
-                                float* __restrict__ of, bf16_t* __restrict__ op, long ps, int planes, int act,
+                                float* __restrict__ of, op16_t* __restrict__ op, long ps, int planes, int act,
                                 const float* __restrict__ aa, const float* __restrict__ ab, long total) {
   const int pad = (ktaps - 1) / 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -504,7 +505,7 @@ __global__ void wn_scale_kernel(const float* __restrict__ v, const float* __rest
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ src, const float* __restrict__ scale,
-                                   bf16_t* __restrict__ dst, long ps, int planes, int mode, int N, int K,
+                                   op16_t* __restrict__ dst, long ps, int planes, int mode, int N, int K,
                                    int Cin, int Cout, int kw, int stride) {
   const long total = (long)N * K;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -549,7 +550,7 @@ __global__ void snake_params_kernel(const float* __restrict__ alpha, const float
 }  // namespace
 
 // =========================================================================== launchers
-void launch_pack_tokens(const float* s0, int C0, const float* s1, int C1, int B, int T, float* df, bf16_t* dp,
+void launch_pack_tokens(const float* s0, int C0, const float* s1, int C1, int B, int T, float* df, op16_t* dp,
                         long ps, int planes, hipStream_t st) {
   const long n = (long)B * T * (C0 + C1);
   hipLaunchKernelGGL(pack_tokens_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, s0, C0, s1, C1, B, T, df, dp, ps,
@@ -558,7 +559,7 @@ void launch_pack_tokens(const float* s0, int C0, const float* s1, int C1, int B,
 void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hipStream_t st) {
   hipLaunchKernelGGL(unpack_tokens_kernel, dim3(grid_for((long)B * C * T)), dim3(TPB), 0, st, src, dst, B, C, T);
 }
-void launch_to_planes(const float* src, bf16_t* dst, long ps, int planes, long n, hipStream_t st) {
+void launch_to_planes(const float* src, op16_t* dst, long ps, int planes, long n, hipStream_t st) {
   hipLaunchKernelGGL(to_planes_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, st, src, dst, ps, planes, n / 4);
 }
 void launch_pc_prior(const float* y, const float* z, float* x, float stdT, int B, int n, int D, int T,
@@ -578,13 +579,13 @@ void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, c
   hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G,
                      n, D, T, total);
 }
-void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, bf16_t* out, long ps,
+void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, op16_t* out, long ps,
                              int planes, int rows, int D, float eps, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_planes_kernel, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, gamma, beta, out, ps,
                      planes, rows, D, eps);
 }
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
-                          const float* gamma, const float* beta, bf16_t* out, long ps, int planes, int rows, int D,
+                          const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
                           float eps, int do_norm, hipStream_t st) {
   if (D <= 1024)
     hipLaunchKernelGGL(residual_norm_kernel<4>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
@@ -593,7 +594,7 @@ void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_str
     hipLaunchKernelGGL(residual_norm_kernel<16>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
                        slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm);
 }
-void launch_timestep_features(const float* t, const float* w, int B, int half, bf16_t* out, long ps, int planes,
+void launch_timestep_features(const float* t, const float* w, int B, int half, op16_t* out, long ps, int planes,
                               hipStream_t st) {
   hipLaunchKernelGGL(timestep_features_kernel, dim3(grid_for((long)B * half)), dim3(TPB), 0, st, t, w, B, half,
                      out, ps, planes);
@@ -601,7 +602,7 @@ void launch_timestep_features(const float* t, const float* w, int B, int half, b
 void launch_rope_tables(float* ct, float* stb, int S, int rot, hipStream_t st) {
   hipLaunchKernelGGL(rope_tables_kernel, dim3(grid_for((long)S * rot)), dim3(TPB), 0, st, ct, stb, S, rot);
 }
-void launch_attention(const float* qkv, const float* rc, const float* rs, int rot, bf16_t* out, long ps,
+void launch_attention(const float* qkv, const float* rc, const float* rs, int rot, op16_t* out, long ps,
                       int planes, int B, int S, int H, int dh, hipStream_t st) {
   (void)dh;
   const size_t sm = (size_t)S * (64 + 4 + 64) * sizeof(float);
@@ -613,7 +614,7 @@ void launch_attention(const float* qkv, const float* rc, const float* rs, int ro
   }
   hipLaunchKernelGGL(attention_kernel<64>, dim3(B * H), dim3(TPB), sm, st, qkv, rc, rs, rot, out, ps, planes, S, H);
 }
-void launch_conv_out1(const bf16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
+void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
                       int ktaps, int apply_tanh, hipStream_t st) {
   const size_t sm = ((size_t)(64 + ktaps - 1) * (C + 4) + (size_t)ktaps * C + 256) * sizeof(float);
   static bool attr_set = false;
@@ -627,7 +628,7 @@ void launch_conv_out1(const bf16_t* a, long ps, int planes, const float* w, floa
                      apply_tanh);
 }
 void launch_conv_in1(const float* wav, const float* w, const float* bias, int S, int L, int Cout, int ktaps,
-                     float* of, bf16_t* op, long ps, int planes, int act, const float* aa, const float* ab,
+                     float* of, op16_t* op, long ps, int planes, int act, const float* aa, const float* ab,
                      hipStream_t st) {
   const long total = (long)S * L * Cout;
   hipLaunchKernelGGL(conv_in1_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, wav, w, bias, L, Cout, ktaps, of, op,
@@ -643,7 +644,7 @@ void launch_randn(float* out, long n, unsigned long long seed, unsigned long lon
 void launch_wn_scale(const float* v, const float* g, float* scale, int R, long inner, hipStream_t st) {
   hipLaunchKernelGGL(wn_scale_kernel, dim3(cdiv(R, 4)), dim3(TPB), 0, st, v, g, scale, R, inner);
 }
-void launch_pack_weight(const float* src, const float* scale, bf16_t* dst, long ps, int planes, int mode, int N,
+void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long ps, int planes, int mode, int N,
                         int K, int Cin, int Cout, int kw, int stride, hipStream_t st) {
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)N * K)), dim3(TPB), 0, st, src, scale, dst, ps, planes,
                      mode, N, K, Cin, Cout, kw, stride);

@@ -31,6 +31,8 @@ extern "C" {
 
 #define DSN_PREC_BF16 1    /* bf16 MFMA operands, fp32 accumulate                  */
 #define DSN_PREC_BF16X3 2  /* split-bf16 (hi,lo) operands: 3 bf16 MFMAs per product */
+#define DSN_PREC_FP16 3    /* fp16 MFMA operands (11-bit mantissa), fp32 accumulate */
+#define DSN_PREC_FP16X3 4  /* split-fp16 (hi,lo) operands: 3 fp16 MFMAs per product */
 
 #define DSN_SCORE_NONE 0
 #define DSN_SCORE_DIT 1    /* reference src/stable_audio_tools/models/dit.py:12-244  */
