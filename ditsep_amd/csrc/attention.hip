@@ -1,0 +1,202 @@
+// MFMA attention for the DiT score network on gfx950 (latent sequences: 33 .. 256 tokens,
+// 64-wide heads).  One wave per (batch item, head).
+//
+// Inputs are the operand planes the fused QKV GEMM epilogue wrote: q (rotary applied,
+// pre-scaled by 1/sqrt(dh)) | k (rotary applied) | v, token-major [B*S][3*D].
+//
+//   scores^T[key][query] = K Q^T     MFMA-A = K rows, MFMA-B = Q rows: both fragments are 16-byte
+//                                    row reads straight from global memory, no LDS.
+//   softmax over keys                each lane owns ONE query column (lane & 15) and 4 keys per key
+//                                    tile (rows 4*(lane>>4) + r): in-lane max/sum + two xor-shuffles.
+//   O^T[d][query] = V^T P^T          the un-normalised probabilities stay where the first MFMA left
+//                                    them and ARE the B operand of the second one: MFMA k-slot
+//                                    (g, jj) is bound to key 16*(2u + jj/4) + 4g + (jj & 3), and the
+//                                    V^T fragment is fetched in that same order with
+//                                    ds_read_b64_tr_b16 (hardware-transposed LDS read of a
+//                                    4-key x 16-feature block) -- no lane movement anywhere.
+// Each lane ends with 4 consecutive features of one query -> 8-byte channels-last stores of the
+// operand planes the out-projection GEMM consumes.
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int P, int F16, int NKT>
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __restrict__ qkv, long ps,
+                                                            op16_t* __restrict__ out, long out_ps, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][nkt*16][64]
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int D = H * 64;
+  const long rs = 3L * D;  // token row stride
+  const op16_t* qb = qkv + (long)b * S * rs + h * 64;
+  const op16_t* kb = qb + D;
+  const op16_t* vb = qb + 2 * D;
+  const int nkt = (S + 15) >> 4;
+  const int vrows = nkt * 16;
+
+  // stage V (zero beyond S) -- 8 lanes x 16 B per token row
+  const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int idx = lane; idx < vrows * 8; idx += 64) {
+    const int row = idx >> 3, c = idx & 7;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const op16x8 v = row < S ? *reinterpret_cast<const op16x8*>(vb + p * ps + row * rs + c * 8) : zero8;
+      *reinterpret_cast<op16x8*>(vlds + ((long)p * vrows + row) * 64 + c * 8) = v;
+    }
+  }
+  __syncthreads();
+
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;  // role inside a 16-lane transposed-read group
+
+  for (int qt = 0; qt < nkt; ++qt) {
+    // ---- scores^T = K Q^T -------------------------------------------------
+    const int qrow = min(qt * 16 + r16, S - 1);
+    op16x8 fq[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        fq[p][ks] = *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
+    f32x4 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        const int krow = min(kt * 16 + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          op16x8 fk[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            fk[p] = *reinterpret_cast<const op16x8*>(kb + p * ps + krow * rs + ks * 32 + g * 8);
+          if (P == 2) {
+            sc[kt] = mfma16<F16>(fk[P - 1], fq[0][ks], sc[kt]);
+            sc[kt] = mfma16<F16>(fk[0], fq[P - 1][ks], sc[kt]);
+          }
+          sc[kt] = mfma16<F16>(fk[0], fq[0][ks], sc[kt]);
+        }
+      }
+    }
+    // ---- softmax over keys (this lane: query qt*16 + r16, keys kt*16 + 4g + r) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
+          mx = fmaxf(mx, sc[kt][r]);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = kt < nkt ? expf(sc[kt][r] - mx) : 0.f;  // exp(-inf) = 0 for masked keys
+        sc[kt][r] = pv;
+        lsum += pv;
+      }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+
+    // ---- O^T = V^T P^T ----------------------------------------------------------
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      if (2 * u < nkt) {
+        op16x8 fp[P];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float pv = jj < 4 ? sc[2 * u][jj] : sc[2 * u + 1][jj - 4];
+          op16_t hi, lo;
+          dsn_split(pv, hi, lo, F16);
+          fp[0][jj] = hi;
+          if (P == 2) fp[P - 1][jj] = lo;
+        }
+        const bool second = 2 * u + 1 < nkt;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          op16x8 fv[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const op16_t* base = vlds + (long)p * vrows * 64 + dt * 16 + 4 * tp;
+            const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base + ((2 * u) * 16 + 4 * g + tq) * 64));
+            // rows of a tile past the sequence end are zero-filled in LDS; clamp the address only
+            const int t1 = second ? 2 * u + 1 : 2 * u;
+            s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base + (t1 * 16 + 4 * g + tq) * 64));
+            if (!second) hi4 = s16x4{0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              fv[p][e] = (unsigned short)lo4[e];
+              fv[p][4 + e] = (unsigned short)hi4[e];
+            }
+          }
+          if (P == 2) {
+            oacc[dt] = mfma16<F16>(fv[P - 1], fp[0], oacc[dt]);
+            oacc[dt] = mfma16<F16>(fv[0], fp[P - 1], oacc[dt]);
+          }
+          oacc[dt] = mfma16<F16>(fv[0], fp[0], oacc[dt]);
+        }
+      }
+    }
+    // ---- normalise + store planes: query qt*16 + r16, features dt*16 + 4g + r --------
+    const int qi = qt * 16 + r16;
+    if (qi < S) {
+      const float inv = 1.f / lsum;
+      const long obase = ((long)b * S + qi) * D + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        op16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          op16_t a, c;
+          dsn_split(oacc[dt][r] * inv, a, c, F16);
+          hi[r] = a;
+          lo[r] = c;
+        }
+        *reinterpret_cast<op16x4*>(out + obase + dt * 16) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(out + out_ps + obase + dt * 16) = lo;
+      }
+    }
+  }
+}
+
+template <int P, int F16>
+void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S, int H, hipStream_t st) {
+  const int nkt = (S + 15) / 16;
+  const size_t sm = (size_t)P * nkt * 16 * 64 * sizeof(op16_t);
+  if (nkt <= 4) {
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S, H);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<P, F16, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S, H);
+  }
+}
+
+}  // namespace
+
+void launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H,
+                           hipStream_t st) {
+  const int P = PL_COUNT(pl), f16 = PL_F16(pl);
+  if (P == 1 && !f16) launch_t<1, 0>(qkv, ps, out, out_ps, B, S, H, st);
+  else if (P == 2 && !f16) launch_t<2, 0>(qkv, ps, out, out_ps, B, S, H, st);
+  else if (P == 1) launch_t<1, 1>(qkv, ps, out, out_ps, B, S, H, st);
+  else launch_t<2, 1>(qkv, ps, out, out_ps, B, S, H, st);
+}

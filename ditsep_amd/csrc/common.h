@@ -52,6 +52,16 @@ __device__ __forceinline__ void dsn_split(float v, op16_t& hi, op16_t& lo, int f
   lo = to_op16(v - from_op16(hi, f16), f16);
 }
 
+// one v_mfma_f32_16x16x32 on raw 16-bit operand fragments: D[n][m] += sum_k w[n][k] a[m][k]
+template <int F16>
+__device__ __forceinline__ f32x4 mfma16(const op16x8& w, const op16x8& a, const f32x4& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0,
+                                                   0);
+}
+
 // wave-wide reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -524,7 +524,7 @@ struct dsn_ctx {
     op16_t* H0 = wsbuf<op16_t>("dit_H0", Mt * din * P);
     float* X = wsbuf<float>("dit_X", M * D);
     op16_t* Ap = wsbuf<op16_t>("dit_Ap", M * D * P);
-    float* QKV = wsbuf<float>("dit_QKV", M * 3 * D);
+    op16_t* QKVp = wsbuf<op16_t>("dit_QKVp", M * 3 * D * P);
     op16_t* FF = wsbuf<op16_t>("dit_FF", M * 4 * D * P);
     op16_t* TF = wsbuf<op16_t>("dit_TF", (long)B * 256 * P);
     op16_t* TE = wsbuf<op16_t>("dit_TE", (long)B * D * P);
@@ -578,12 +578,18 @@ struct dsn_ctx {
       const DitLayer& L = layers[i];
       launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
                            st);
-      {
+      {  // q|k|v operand planes: rotary + 1/sqrt(dh) fused into the epilogue
         GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
-        d.out_f32 = QKV;
+        d.out_planes = QKVp;
+        d.out_ps = M * 3 * D;
+        d.rope_cos = rc;
+        d.rope_sin = rs;
+        d.rope_S = S;
+        d.qkv_D = D;
+        d.q_scale = 0.125f;
         run(d, st);
       }
-      launch_attention(QKV, rc, rs, rot, Ap, M * D, PL, B, S, H, 64, st);
+      launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         d.ksplit = pick_ksplit(d);

@@ -46,6 +46,12 @@ struct GemmDesc {
   // The consumer (residual_norm kernel) adds bias + residual + slabs.
   int ksplit;
   long slab_stride;
+  // fused QKV epilogue (DiT): rotary tables [rope_S][32] (cos | sin), token position = m % rope_S,
+  // sections q | k | v of width qkv_D, 64-wide heads; q scaled by q_scale.  null = off.
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_S, qkv_D;
+  float q_scale;
 };
 
 // launchers (igemm.hip)

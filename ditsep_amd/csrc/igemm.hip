@@ -25,13 +25,132 @@ constexpr int TILE_ELEMS = 128 * BK;  // one operand plane tile
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
 
-template <int F16>
-__device__ __forceinline__ f32x4 mfma16(const op16x8& w, const op16x8& a, const f32x4& c) {
-  if (F16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0,
-                                                   0);
+template <int P, int F16>
+__device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
+                                              int z) {
+  const int nq = (lane >> 4) * 4;
+  if (d.ksplit > 1) {  // raw partial sums to this slice's slab
+    float* slab = d.out_f32 + (long)z * d.slab_stride;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = mw0 + tm * 16 + (lane & 15);
+      if (m >= d.M) continue;
+      const int b = m / d.rows_per_b;
+      const int j = m - b * d.rows_per_b;
+      const long row_rel = (long)j * d.out_row_elems + d.out_off;
+      const long row_abs = (long)b * d.out_bstride + row_rel;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const long rel = row_rel + n;
+        if (rel < 0 || rel >= d.out_limit) continue;
+        *reinterpret_cast<f32x4*>(slab + row_abs + n) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = mw0 + tm * 16 + (lane & 15);
+    if (m >= d.M) continue;
+    const int b = m / d.rows_per_b;
+    const int j = m - b * d.rows_per_b;
+    const long row_rel = (long)j * d.out_row_elems + d.out_off;
+    const long row_abs = (long)b * d.out_bstride + row_rel;
+    if (!d.swiglu) {
+      if (d.rope_cos) {
+        // fused QKV epilogue: this wave's 64 columns are one 64-wide head of the q, k or v section;
+        // rotary embedding on the first 32 features (pairs (c, c+16) = accumulator tiles 0 and 1 of the
+        // same lane), q pre-scaled by 1/sqrt(dh)
+        const int section = nw0 / d.qkv_D;
+        if (section < 2) {
+          const int pos = m % d.rope_S;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + nq);
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + nq);
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + 16 + nq);
+          const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + 16 + nq);
+          const f32x4 x0 = acc[0][tm], x1 = acc[1][tm];
+          acc[0][tm] = x0 * c0 - x1 * s0;
+          acc[1][tm] = x1 * c1 + x0 * s1;
+          if (section == 0) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tn][tm] *= d.q_scale;
+          }
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const long rel = row_rel + n;
+        if (rel < 0 || rel >= d.out_limit) continue;
+        const long off = row_abs + n;
+        f32x4 v = acc[tn][tm];
+        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
+        v *= d.out_scale;
+        if (d.out_f32) {
+          f32x4 o = v;
+          if (d.f32_op == DSN_F32_TANH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
+          }
+          *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
+        }
+        if (d.out_planes) {
+          f32x4 a = v;
+          if (d.act == DSN_ACT_ELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_elu(v[r]);
+          } else if (d.act == DSN_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_silu(v[r]);
+          } else if (d.act == DSN_ACT_SNAKE) {
+            const int ch = n % d.act_mod;
+            const f32x4 al = *reinterpret_cast<const f32x4*>(d.act_a + ch);
+            const f32x4 ib = *reinterpret_cast<const f32x4*>(d.act_b + ch);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
+          }
+          op16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            op16_t h, l;
+            dsn_split(a[r], h, l, F16);
+            hi[r] = h;
+            lo[r] = l;
+          }
+          *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
+        }
+      }
+    } else {
+      // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int np = nw0 + tp * 32;
+        if (np >= d.N) continue;
+        const int feat = (np >> 1) + nq;
+        const long off = row_abs + feat;
+        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
+        if (d.bias) {
+          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
+          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
+        }
+        op16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          op16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
+          hi[r] = h;
+          lo[r] = l;
+        }
+        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
+      }
+    }
+  }
 }
 
 template <int P, int F16>
@@ -157,92 +276,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
     __syncthreads();
   }
 
-  // ------------------------------- epilogue ---------------------------------
-  const int nq = (lane >> 4) * 4;  // first of this lane's 4 consecutive channels inside a 16-tile
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
-    if (m >= d.M) continue;
-    const int b = m / d.rows_per_b;
-    const int j = m - b * d.rows_per_b;
-    const long row_rel = (long)j * d.out_row_elems + d.out_off;
-    const long row_abs = (long)b * d.out_bstride + row_rel;
-    if (!d.swiglu) {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int n = n0 + wn * 64 + tn * 16 + nq;
-        if (n >= d.N) continue;
-        const long rel = row_rel + n;
-        if (rel < 0 || rel >= d.out_limit) continue;
-        const long off = row_abs + n;
-        f32x4 v = acc[tn][tm];
-        if (d.bias) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
-          v += bb;
-        }
-        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
-        v *= d.out_scale;
-        if (d.out_f32) {
-          f32x4 o = v;
-          if (d.f32_op == DSN_F32_TANH) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
-          }
-          *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
-        }
-        if (d.out_planes) {
-          f32x4 a = v;
-          if (d.act == DSN_ACT_ELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_elu(v[r]);
-          } else if (d.act == DSN_ACT_SILU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_silu(v[r]);
-          } else if (d.act == DSN_ACT_SNAKE) {
-            const int ch = n % d.act_mod;
-            const f32x4 al = *reinterpret_cast<const f32x4*>(d.act_a + ch);
-            const f32x4 ib = *reinterpret_cast<const f32x4*>(d.act_b + ch);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
-          }
-          op16x4 hi, lo;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            op16_t h, l;
-            dsn_split(a[r], h, l, F16);
-            hi[r] = h;
-            lo[r] = l;
-          }
-          *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
-          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
-        }
-      }
-    } else {
-      // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
-        const int np = n0 + wn * 64 + tp * 32;  // packed row of the value tile
-        if (np >= d.N) continue;
-        const int feat = (np >> 1) + nq;
-        const long off = row_abs + feat;
-        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
-        if (d.bias) {
-          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
-          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
-        }
-        op16x4 hi, lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          op16_t h, l;
-          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
-          hi[r] = h;
-          lo[r] = l;
-        }
-        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
-        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
-      }
-    }
-  }
+  epilogue_tile<P, F16>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, 0);
 }
 
 }  // namespace
@@ -279,114 +313,6 @@ hipError_t igemm_launch(const GemmDesc& din, int pl, hipStream_t stream) {
 // fall outside the sequence (conv zero padding, M/N tails) read a zero page.
 // ============================================================================
 namespace {
-
-template <int P, int F16>
-__device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
-                                              int z) {
-  const int nq = (lane >> 4) * 4;
-  if (d.ksplit > 1) {  // raw partial sums to this slice's slab
-    float* slab = d.out_f32 + (long)z * d.slab_stride;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      const int m = mw0 + tm * 16 + (lane & 15);
-      if (m >= d.M) continue;
-      const int b = m / d.rows_per_b;
-      const int j = m - b * d.rows_per_b;
-      const long row_rel = (long)j * d.out_row_elems + d.out_off;
-      const long row_abs = (long)b * d.out_bstride + row_rel;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int n = nw0 + tn * 16 + nq;
-        if (n >= d.N) continue;
-        const long rel = row_rel + n;
-        if (rel < 0 || rel >= d.out_limit) continue;
-        *reinterpret_cast<f32x4*>(slab + row_abs + n) = acc[tn][tm];
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = mw0 + tm * 16 + (lane & 15);
-    if (m >= d.M) continue;
-    const int b = m / d.rows_per_b;
-    const int j = m - b * d.rows_per_b;
-    const long row_rel = (long)j * d.out_row_elems + d.out_off;
-    const long row_abs = (long)b * d.out_bstride + row_rel;
-    if (!d.swiglu) {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int n = nw0 + tn * 16 + nq;
-        if (n >= d.N) continue;
-        const long rel = row_rel + n;
-        if (rel < 0 || rel >= d.out_limit) continue;
-        const long off = row_abs + n;
-        f32x4 v = acc[tn][tm];
-        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
-        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
-        v *= d.out_scale;
-        if (d.out_f32) {
-          f32x4 o = v;
-          if (d.f32_op == DSN_F32_TANH) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
-          }
-          *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
-        }
-        if (d.out_planes) {
-          f32x4 a = v;
-          if (d.act == DSN_ACT_ELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_elu(v[r]);
-          } else if (d.act == DSN_ACT_SILU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_silu(v[r]);
-          } else if (d.act == DSN_ACT_SNAKE) {
-            const int ch = n % d.act_mod;
-            const f32x4 al = *reinterpret_cast<const f32x4*>(d.act_a + ch);
-            const f32x4 ib = *reinterpret_cast<const f32x4*>(d.act_b + ch);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = dsn_snake(v[r], al[r], ib[r]);
-          }
-          op16x4 hi, lo;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            op16_t h, l;
-            dsn_split(a[r], h, l, F16);
-            hi[r] = h;
-            lo[r] = l;
-          }
-          *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
-          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
-        }
-      }
-    } else {
-      // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
-        const int np = nw0 + tp * 32;
-        if (np >= d.N) continue;
-        const int feat = (np >> 1) + nq;
-        const long off = row_abs + feat;
-        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
-        if (d.bias) {
-          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
-          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
-        }
-        op16x4 hi, lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          op16_t h, l;
-          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
-          hi[r] = h;
-          lo[r] = l;
-        }
-        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
-        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
-      }
-    }
-  }
-}
 
 template <int P, int F16, int TBM, int TBN, int NST>
 __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,

@@ -38,6 +38,10 @@ void launch_timestep_features(const float* t, const float* w, int B, int half, o
 // rope_cos/sin [S][rot] fp32 tables (freqs duplicated over the two halves).
 void launch_attention(const float* qkv, const float* rope_cos, const float* rope_sin, int rot, op16_t* out,
                       long ps, int planes, int B, int S, int H, int dh, hipStream_t s);
+// MFMA attention over operand planes q|k|v [B*S][3*H*64] written by the fused QKV epilogue
+// (attention.hip); S <= 256.
+void launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H,
+                           hipStream_t s);
 void launch_rope_tables(float* cos_t, float* sin_t, int S, int rot, hipStream_t s);
 
 // ---- Oobleck edges -------------------------------------------------------------

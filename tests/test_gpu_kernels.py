@@ -245,3 +245,19 @@ def test_graph_replay_matches_eager():
     xg, _ = eng.pc_sample(y2, noise, N=3)
     assert torch.equal(xe, xg)
     eng.close()
+
+
+@pytest.mark.parametrize("T,prec,tol", [(100, X3, 1e-4), (235, FP16, 4e-3), (17, FP16X3, 1e-5)])
+def test_dit_long_sequences(T, prec, tol):
+    """Latent sequences beyond one 64-key block (the 16-key-tile attention variant); T=235 is the
+    30 s long-form shape of BASELINE config 5."""
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 13)
+    g = torch.Generator().manual_seed(14)
+    xt = 2.0 * torch.randn((2, 2, 64, T), generator=g)
+    mix = torch.randn((2, 1, 64, T), generator=g)
+    t = torch.tensor([0.7, 0.2])
+    ref = odit.DiTScore(sd, cfg)(xt, t, mix)
+    eng = make_engine(cfg, sd, precision=prec)
+    assert rel_l2(eng.score(xt, t, mix), ref) < tol
+    eng.close()
