@@ -1234,8 +1234,8 @@ int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int 
     HIPCHK(hipEventCreate(&e1));
     auto launch = [&] {
       hipError_t e = variant == 1 ? igemm_launch(d, PL, nullptr)
-                                  : igemm2_launch_cfg(d, PL, (variant >> 8) & 0xfff, (variant >> 20) & 0xfff,
-                                                      variant & 0xff, nullptr);
+                                  : igemm2_launch_cfg(d, PL, (variant >> 8) & 0xfff, (variant >> 20) & 0x3ff,
+                                                      variant & 0xf, (variant & 0x10) ? 64 : 32, nullptr);
       if (e != hipSuccess) fail(DSN_EHIP, "bench launch: %s", hipGetErrorString(e));
     };
     launch();

@@ -57,5 +57,5 @@ struct GemmDesc {
 // launchers (igemm.hip)
 hipError_t igemm_launch(const GemmDesc& d, int pl, hipStream_t stream);   // v1: register-staged
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream);  // v2: glds ring + split-K, auto tile
-hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, hipStream_t stream);
+hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, int bk, hipStream_t stream);
 // `pl` = DSN_PL(plane count, fp16 flag)

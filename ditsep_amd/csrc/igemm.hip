@@ -314,19 +314,29 @@ hipError_t igemm_launch(const GemmDesc& din, int pl, hipStream_t stream) {
 // ============================================================================
 namespace {
 
-template <int P, int F16, int TBM, int TBN, int NST>
+// swizzle of the 16-byte chunk index inside a TBK-wide LDS row (conflict-free ds_read_b128 of
+// MFMA fragments: rows 64 B -> 4 rows per 256-B bank window, rows 128 B -> 2 rows per window)
+template <int TBK>
+__device__ __forceinline__ int swzk(int row) {
+  return TBK == 32 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
+}
+
+template <int P, int F16, int TBM, int TBN, int NST, int TBK>
 __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,
                                                                                  const op16_t* __restrict__ zero_page) {
-  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows][32]
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows][TBK]
   constexpr int WN_ = TBN / 64;
   constexpr int NWAVES = (TBM / 64) * WN_;
   constexpr int ROWS = TBM + TBN;             // staged rows per plane per k-tile (A rows then W rows)
-  constexpr int PLANE_ELEMS = ROWS * BK;
+  constexpr int PLANE_ELEMS = ROWS * TBK;
   constexpr int STAGE_ELEMS = P * PLANE_ELEMS;
-  constexpr int GROUPS = ROWS / 16;           // 16-row glds groups per plane
+  constexpr int CPR = TBK / 8;                // 16-byte chunks per row
+  constexpr int RPG = 64 / CPR;               // rows filled by one glds wave-instruction (1 KiB)
+  constexpr int GROUPS = ROWS / RPG;
   constexpr int GPW = GROUPS / NWAVES;        // groups per wave
   static_assert(GROUPS % NWAVES == 0, "row groups must divide over the waves");
   constexpr int G = GPW * P;                  // glds wave-instructions per wave per k-tile
+  constexpr int KS = TBK / 32;                // MFMA k-steps per k-tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
   const int Ktot = d.taps * d.Cin;
-  const int kc_per_tap = d.Cin / BK;
+  const int kc_per_tap = d.Cin / TBK;
   const int nkt_all = d.taps * kc_per_tap;
   const int kt_begin = (int)((long)nkt_all * z / d.ksplit);
   const int kt_end = (int)((long)nkt_all * (z + 1) / d.ksplit);
@@ -351,9 +361,8 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 
   // ---- loader role: this wave stages row groups [wave*GPW, wave*GPW + GPW) ----
   // unified row addressing: r = js + tap*dil must lie in [0, lim);
-  // element offset = base + r*row_elems + tap*tap_elems + kc*BK
-  const int rsub = lane >> 2, cpos = lane & 3;
-  const int gchunk = cpos ^ ((-(lane >> 4)) & 3);  // source chunk held by this lane's LDS slot
+  // element offset = base + r*row_elems + tap*tap_elems + kc*TBK
+  const int rsub = lane / CPR, cpos = lane % CPR;
   const op16_t* r_src[GPW];
   long r_ps[GPW];
   int r_js[GPW], r_dil[GPW];
@@ -363,8 +372,9 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave * GPW + gi;
-    const bool is_a = g < TBM / 16;
-    const int row = (is_a ? g : g - TBM / 16) * 16 + rsub;
+    const bool is_a = g < TBM / RPG;
+    const int row = (is_a ? g : g - TBM / RPG) * RPG + rsub;
+    const int gchunk = cpos ^ swzk<TBK>(row);  // source chunk held by this lane's LDS slot
     const int m = m0 + row;
     const int b = m / d.rows_per_b;
     const int j = m - b * d.rows_per_b;
@@ -383,17 +393,17 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   auto issue = [&](int kt, int stage) {
     const int tap = kt / kc_per_tap;
     const int kc = kt - tap * kc_per_tap;
-    op16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * 16 * BK;
+    op16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * RPG * TBK;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int r = r_js[gi] + tap * r_dil[gi];
       const bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
-      const op16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * BK;
+      const op16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * TBK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const op16_t* g = ok ? g0 + p * r_ps[gi] : zsrc;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + gi * 16 * BK),
+                                         (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + gi * RPG * TBK),
                                          16, 0, 0);
       }
     }
@@ -405,10 +415,11 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // fragment rows are (tile*16 + frow) with tile offsets multiples of 16: the swizzle only sees frow
   const int frow = lane & 15, fchunk = lane >> 4;
-  const int fsw = swz(frow, fchunk) * 8;
-  const int a_frag_off = (wm * 64 + frow) * BK + fsw;
-  const int w_frag_off = (TBM + wn * 64 + frow) * BK + fsw;
+  const int fsw = swzk<TBK>(frow);
+  const int a_row_off = (wm * 64 + frow) * TBK;
+  const int w_row_off = (TBM + wn * 64 + frow) * TBK;
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -427,24 +438,28 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     if (i + NST - 1 < nkt) issue(kt_begin + i + NST - 1, (i + NST - 1) % NST);
 
     const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
-    op16x8 fa[P][4], fw[P][4];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = ((ks * 4 + fchunk) ^ fsw) * 8;
+      op16x8 fa[P][4], fw[P][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        fa[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_frag_off + k * 16 * BK);
-        fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_frag_off + k * 16 * BK);
-      }
-    }
+      for (int p = 0; p < P; ++p) {
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-        if (P == 2) {
-          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
-          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
+        for (int k = 0; k < 4; ++k) {
+          fa[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + k * 16 * TBK + coff);
+          fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * TBK + coff);
         }
-        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          if (P == 2) {
+            acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
+            acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
+          }
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
+        }
       }
     }
   }
@@ -460,66 +475,84 @@ const op16_t* zero_page() {
   return zp;
 }
 
-template <int P, int F16, int TBM, int TBN, int NST>
+template <int P, int F16, int TBM, int TBN, int NST, int TBK>
 hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = cdiv(d.M, TBM);
   d.tiles_n = cdiv(d.N, TBN);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * P * (TBM + TBN) * BK * sizeof(op16_t);
-  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
+  const size_t smem = (size_t)NST * P * (TBM + TBN) * TBK * sizeof(op16_t);
+  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST, TBK>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
                      d, zp);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// cfg: 0 = auto; otherwise BM/128 + 2*(BN/128) + 4*stages packed as  (bm_code | bn_code<<4 | nst<<8)
-hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int nst, hipStream_t stream) {
+hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int nst, int bk, hipStream_t stream) {
   const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
-  if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
+  if (d.Cin % bk != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define CFG(P_, BM_, BN_, NS_)                                           \
-  if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_)              \
-    return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_>(d, zp, stream) : launch_cfg<P_, 0, BM_, BN_, NS_>(d, zp, stream);
-  CFG(2, 128, 128, 2) CFG(2, 128, 128, 3) CFG(2, 256, 128, 2) CFG(2, 128, 256, 2) CFG(2, 256, 256, 2)
-  CFG(2, 256, 128, 3) CFG(2, 128, 256, 3)
-  CFG(1, 128, 128, 3) CFG(1, 128, 128, 4) CFG(1, 256, 128, 3) CFG(1, 128, 256, 3) CFG(1, 256, 256, 2)
-  CFG(1, 256, 256, 3) CFG(1, 256, 128, 4) CFG(1, 128, 256, 4)
+#define CFG(P_, BM_, BN_, NS_, BK_)                                                   \
+  if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)              \
+    return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_>(d, zp, stream)                 \
+               : launch_cfg<P_, 0, BM_, BN_, NS_, BK_>(d, zp, stream);
+  // split (2-plane) modes: 48 MFMAs per wave per 32-deep k-tile already amortise the barrier
+  CFG(2, 128, 128, 2, 32) CFG(2, 256, 128, 2, 32) CFG(2, 128, 256, 2, 32) CFG(2, 256, 256, 2, 32)
+  CFG(2, 256, 128, 3, 32)
+  // single-plane modes
+  CFG(1, 128, 128, 3, 32) CFG(1, 256, 128, 3, 32) CFG(1, 256, 256, 3, 32)
+  CFG(1, 128, 128, 2, 64) CFG(1, 128, 128, 3, 64) CFG(1, 256, 128, 2, 64) CFG(1, 128, 256, 2, 64)
+  CFG(1, 256, 256, 2, 64) CFG(1, 256, 128, 3, 64) CFG(1, 128, 256, 3, 64)
 #undef CFG
   return hipErrorInvalidValue;
 }
 
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
   const int planes = PL_COUNT(pl);
-  // Tile choice from the measured sweep (scripts/gemm_bench.py, profiles/): the kernel is
-  // L2->LDS bandwidth bound, so take the biggest tile whose grid still fills 256 CUs.
-  //   large-M convs:  256x256 (N >= 256) -- 16 waves, operand bytes per flop halved
-  //   N == 128 tails: 128x128 (split-bf16) / 256x128 (bf16)
-  //   ConvTranspose phase GEMMs (M ~ 4k, N = s*Cout >= 4k): 256x128, 3 stages
-  //   DiT regime (M ~ 2k): 128x128; split-K chosen by the caller
-  // Very short K (1x1 convs, K <= 256) is epilogue/HBM bound: the register-staged core wins.
-  int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3;
-  if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, pl, stream);
-  if (d.M >= 8192) {
+  // Tile choice from the measured sweeps (scripts/gemm_bench.py; profiles/r01_gemm_sweep_*.log).
+  // The kernel is L2->LDS bound and, at the DiT's M ~ 2k rows, wave-quantisation bound: take the
+  // biggest tile whose grid still fills 256 CUs.
+  int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
+  const bool k64 = planes == 1 && d.Cin % 64 == 0;
+  if (planes == 2) {
+    // split (hi,lo) operands: 48 MFMAs per wave per 32-deep k-tile
+    if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, pl, stream);  // epilogue-bound 1x1 convs
+    if (d.M >= 8192) {
+      if (d.N >= 256) bm = bn = 256;
+    } else if (d.M >= 4096 && d.N >= 4096) {
+      bm = 256;
+      nst = 3;
+    }
+  } else if (d.M >= 8192) {                  // large-M conv stacks
     if (d.N >= 256) {
       bm = bn = 256;
-    } else if (planes == 1) {
+      if (k64) { nst = 2; bk = 64; }
+    } else {
       bm = 256;
     }
-  } else if (d.M >= 4096 && d.N >= 4096) {
+  } else if (d.M >= 4096 && d.N >= 4096) {   // ConvTranspose phase GEMMs
+    bm = bn = 256;
+    if (k64) { nst = 2; bk = 64; } else { bn = 128; }
+  } else if (d.N >= 4096) {                  // DiT FF-in
     bm = 256;
-    nst = 3;
+  } else if (d.N >= 2048 && k64) {           // DiT QKV
+    bm = 256;
+    bk = 64;
+  } else if (d.ksplit > 1 && k64) {          // DiT residual-stream GEMMs, split-K
+    bm = 256;
+    nst = 2;
+    bk = 64;
   }
-  return igemm2_launch_cfg(d, pl, bm, bn, nst, stream);
+  return igemm2_launch_cfg(d, pl, bm, bn, nst, bk, stream);
 }
