@@ -1,0 +1,174 @@
+"""`LatentDiffSep`-shaped facade over the HIP engine (the drop-in boundary).
+
+Mirrors the inference surface of the reference Lightning module
+(reference src/diffsep_latent.py): `encode` :107-118, `decode` :120-128, `forward` :147-148,
+`get_pc_sampler` :406-469, `separate` :471-487, with the same config keys
+(`model.score_model`, `model.vae`, `model.sde`, `model.t_eps`, `model.sampler`,
+`model.n_speakers`) and the same state_dict naming (`score_model.*`, `vae.*`).
+Training, EMA and logging are out of scope.
+"""
+from __future__ import annotations
+
+import json
+import math
+from typing import Any, Mapping, Optional
+
+import torch
+
+from . import native, sdes
+
+
+def _get(cfg: Any, path: str, default=None):
+    cur = cfg
+    for key in path.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, Mapping):
+            cur = cur.get(key, None)
+        else:
+            cur = getattr(cur, key, None)
+    return default if cur is None else cur
+
+
+def _vae_arch(vae_cfg) -> dict:
+    """Read the Oobleck architecture from a stable-audio-tools model config (dict or JSON path;
+    reference src/utils/load_stable_model.py:9-35, autoencoders.py:866-909)."""
+    cfg = vae_cfg
+    path = _get(vae_cfg, "config_path")
+    if path is not None and _get(vae_cfg, "model") is None:
+        with open(path) as fh:
+            cfg = json.load(fh)
+    enc = _get(cfg, "model.encoder.config")
+    dec = _get(cfg, "model.decoder.config")
+    if _get(cfg, "model.encoder.type", "oobleck") != "oobleck" or _get(cfg, "model.decoder.type", "oobleck") != "oobleck":
+        raise NotImplementedError("only Oobleck encoders/decoders are implemented natively")
+    if _get(cfg, "model.bottleneck.type", "vae") != "vae":
+        raise NotImplementedError("only the VAE bottleneck is implemented natively")
+    src = dec if dec is not None else enc
+    return dict(vae_channels=int(_get(src, "channels", 128)), vae_c_mults=tuple(_get(src, "c_mults", (1, 2, 4, 8))),
+                vae_strides=tuple(_get(src, "strides", (2, 4, 8, 8))),
+                latent_dim=int(_get(cfg, "model.latent_dim", _get(dec, "latent_dim", 64))),
+                vae_enc_latent_dim=int(_get(enc, "latent_dim", 128)) if enc is not None else 128,
+                vae_use_snake=bool(_get(src, "use_snake", False)), vae_final_tanh=bool(_get(dec, "final_tanh", True)),
+                vae_has_encoder=enc is not None, vae_has_decoder=dec is not None)
+
+
+_PRECISIONS = {"bf16": native.PREC_BF16, "bf16x3": native.PREC_BF16X3, "fp16": native.PREC_FP16,
+               "fp16x3": native.PREC_FP16X3}
+
+
+class LatentDiffSep:
+    """Native latent-diffusion separator.  `config` is the reference's Hydra tree (a nested dict or an
+    OmegaConf object); `config.model.score_model._target_` selects the score network:
+      * `...DiTScoreModel` / `...DiffusionTransformer`  DiT over latent tokens (kwargs embed_dim, depth,
+        num_heads; io = n_speakers*latent, input_concat = latent)
+      * `...LatentScoreModelNCSNpp`                      the NCSN++ latent U-Net the reference wires in
+    """
+
+    def __init__(self, config, device: int = 0, precision: str = "fp16"):
+        self.config = config
+        self.device_index = device
+        n_src = int(_get(config, "model.n_speakers", 2))
+        sm = _get(config, "model.score_model")
+        target = str(_get(sm, "_target_", ""))
+        args = dict(device=device, precision=_PRECISIONS[precision], n_src=n_src)
+        if target.endswith("DiTScoreModel") or target.endswith("DiffusionTransformer"):
+            args.update(score_kind=native.SCORE_DIT, dit_embed_dim=int(_get(sm, "embed_dim", 1024)),
+                        dit_depth=int(_get(sm, "depth", 24)), dit_heads=int(_get(sm, "num_heads", 16)))
+        elif target.endswith("LatentScoreModelNCSNpp"):
+            raise NotImplementedError("NCSN++ score network: native kernels not available in this build")
+        elif target == "":
+            args.update(score_kind=native.SCORE_NONE)
+        else:
+            raise ValueError(f"unknown score_model _target_ '{target}'")
+        args.update(_vae_arch(_get(config, "model.vae")))
+        self.sde = sdes.OUVESDE(theta=_get(config, "model.sde.theta", 1.5),
+                                sigma_min=_get(config, "model.sde.sigma_min", 0.96),
+                                sigma_max=_get(config, "model.sde.sigma_max", 10.0),
+                                N=_get(config, "model.sde.N", 30))
+        args.update(sde_theta=self.sde.theta, sde_sigma_min=self.sde.sigma_min, sde_sigma_max=self.sde.sigma_max)
+        self.t_eps = float(_get(config, "model.t_eps", 0.03))
+        self.t_max = self.sde.T
+        self.n_src = n_src
+        self.engine = native.Engine(**args)
+        self.max_len_lat = 0
+        self._finalized = False
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Reference checkpoint naming: `score_model.*`, `vae.encoder.*`, `vae.decoder.*`
+        (non-EMA parameters, as evaluate_latent.py:203-208 uses them)."""
+        self.engine.load_state_dict(state_dict)
+        self.engine.finalize()          # raises on a missing tensor: always strict
+        self._finalized = True
+        return self
+
+    def to(self, device):
+        return self
+
+    def eval(self, no_ema: bool = True):
+        return self
+
+    @property
+    def hop_length(self) -> int:
+        return self.engine.hop_length
+
+    # ------------------------------------------------------------------ reference surface
+    @torch.no_grad()
+    def encode(self, mix, target=None, vae_noise=None, seed=0):
+        y = self.engine.encode(mix, vae_noise, seed=seed)
+        self.max_len_lat = max(self.max_len_lat, y.shape[-1])
+        if target is None:
+            return y, None
+        B, n, L = target.shape
+        t = self.engine.encode(target.reshape(B * n, 1, L), None, seed=seed + 1)
+        return y, t.reshape(B, n, *t.shape[2:])
+
+    @torch.no_grad()
+    def decode(self, est, target_dim=None):
+        return self.engine.decode(est, target_dim)
+
+    def forward(self, xt, time, mix):
+        return self.engine.score(xt, time, mix)
+
+    __call__ = forward
+
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, schedule=None, **kwargs):
+        N = self.sde.N if N is None else N
+        sde = self.sde.copy()
+        sde.N = N
+        kwargs = {"eps": self.t_eps, "n_spkrs": self.n_src, **kwargs}
+        if schedule is not None:
+            raise NotImplementedError("scheduled step sizes (get_pc_scheduled_sampler) are not implemented natively")
+        if minibatch is None:
+            return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
+        M = y.shape[0]
+        noise = kwargs.pop("noise", None)
+
+        def batched_sampling_fn():
+            samples, ns = [], []
+            for i in range(int(math.ceil(M / minibatch))):
+                sl = slice(i * minibatch, (i + 1) * minibatch)
+                nz = None if noise is None else noise[:, sl]
+                sampler = sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y[sl],
+                                              noise=nz, **kwargs)
+                s, n = sampler()
+                samples.append(s)
+                ns.append(n)
+            return torch.cat(samples, dim=0), ns
+
+        return batched_sampling_fn
+
+    @torch.no_grad()
+    def separate(self, mix, target_dim=None, latent=False, **kwargs):
+        if not latent:
+            mix, _ = self.encode(mix, None, vae_noise=kwargs.pop("vae_noise", None), seed=kwargs.get("seed") or 0)
+        sampler_kwargs = dict(_get(self.config, "model.sampler", {}) or {})
+        sampler_kwargs.update(kwargs)
+        sampler = self.get_pc_sampler("reverse_diffusion", "ald", mix, **sampler_kwargs)
+        est, *others = sampler()
+        est = self.decode(est, target_dim)
+        return (est, *others)
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,128 @@
+"""Host mirror of the reference sampler library's interface (reference src/sdes/).
+
+`get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, ...)` keeps the
+reference signature and closure return (reference src/sdes/__init__.py:133-193) but
+the whole predictor-corrector loop -- prior draw, N x (annealed-Langevin corrector,
+reverse-diffusion predictor), every score-network call -- runs inside the HIP
+engine as one captured launch sequence.  There is no Python loop and no PyTorch
+fallback: combinations the native path does not implement raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .registry import Registry
+
+PredictorRegistry = Registry("Predictor")
+CorrectorRegistry = Registry("Corrector")
+SDERegistry = Registry("SDE")
+
+
+@SDERegistry.register("ouve")
+class OUVESDE:
+    """Parameter carrier + closed forms of the OU variance-exploding SDE
+    (reference src/sdes/sdes.py:595-698).  The sampling arithmetic lives in the engine
+    (dsn_ouve_schedule / dsn_pc_sample); these torch forms serve callers that query the SDE."""
+
+    def __init__(self, theta, sigma_min, sigma_max, N=1000, **ignored_kwargs):
+        self.theta, self.sigma_min, self.sigma_max, self.N = float(theta), float(sigma_min), float(sigma_max), int(N)
+        self.logsig = float(np.log(self.sigma_max / self.sigma_min))
+
+    @property
+    def T(self):
+        return 1
+
+    def copy(self):
+        return OUVESDE(self.theta, self.sigma_min, self.sigma_max, N=self.N)
+
+    def sde(self, x, t, y):
+        drift = self.theta * (y - x)
+        sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+        return drift, sigma * np.sqrt(2 * self.logsig)
+
+    def _mean(self, x0, t, y):
+        e = torch.exp(-self.theta * t)
+        e = e.reshape(e.shape + (1,) * (x0.ndim - e.ndim))
+        return e * x0 + (1 - e) * y
+
+    def _std(self, t):
+        smin, th, ls = self.sigma_min, self.theta, self.logsig
+        return torch.sqrt(smin**2 * torch.exp(-2 * th * t) * (torch.exp(2 * (th + ls) * t) - 1) * ls / (th + ls))
+
+    def marginal_prob(self, x0, t, y):
+        return self._mean(x0, t, y), self._std(t)
+
+
+@PredictorRegistry.register("reverse_diffusion")
+class ReverseDiffusionPredictor:
+    """Marker: executed natively (reference src/sdes/predictors.py:55-66)."""
+
+
+@PredictorRegistry.register("euler_maruyama")
+class EulerMaruyamaPredictor:
+    """Registered name only; not implemented natively ('next')."""
+
+
+@PredictorRegistry.register("none")
+class NonePredictor:
+    pass
+
+
+@CorrectorRegistry.register("ald")
+class AnnealedLangevinDynamics:
+    """Marker: executed natively (reference src/sdes/correctors.py:58-84)."""
+
+
+@CorrectorRegistry.register("langevin")
+class LangevinCorrector:
+    pass
+
+
+@CorrectorRegistry.register("ald2")
+class AnnealedLangevinDynamics2:
+    pass
+
+
+@CorrectorRegistry.register("none")
+class NoneCorrector:
+    pass
+
+
+def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=None, denoise=True, eps=3e-2,
+                   snr=0.1, corrector_steps=1, probability_flow=False, intermediate=False, n_spkrs=2,
+                   noise=None, seed=None, **kwargs):
+    """Same arguments as the reference; `score_fn` must be a native-backed model (an object exposing
+    `.engine`, e.g. ditsep_amd.LatentDiffSep).  Extra keywords: `noise` (the injected standard-normal
+    draws in reference order, for bit-comparable parity runs) and `seed` (on-device Philox)."""
+    PredictorRegistry.get_by_name(predictor_name)      # ValueError for unknown names, as the reference
+    CorrectorRegistry.get_by_name(corrector_name)
+    engine = getattr(score_fn, "engine", None)
+    if engine is None:
+        raise NotImplementedError("get_pc_sampler needs a native score model (object with `.engine`); "
+                                  "arbitrary Python score functions are not supported (no PyTorch fallback)")
+    if predictor_name != "reverse_diffusion" or corrector_name not in ("ald", "none"):
+        raise NotImplementedError(f"native sampler implements reverse_diffusion + ald (got {predictor_name}, "
+                                  f"{corrector_name})")
+    if not isinstance(sde, OUVESDE):
+        raise NotImplementedError("native sampler implements the OUVE SDE")
+    if probability_flow or intermediate or true_mean is not None:
+        raise NotImplementedError("probability_flow / intermediate / true_mean are not implemented natively")
+    if n_spkrs != engine.n_src:
+        raise ValueError(f"n_spkrs={n_spkrs} but the engine was built for {engine.n_src} sources")
+    if (abs(sde.theta - engine.cfg.sde_theta) > 1e-6 or abs(sde.sigma_min - engine.cfg.sde_sigma_min) > 1e-6
+            or abs(sde.sigma_max - engine.cfg.sde_sigma_max) > 1e-6):
+        raise ValueError("sde parameters differ from the ones the engine was built with")
+    c_steps = 0 if corrector_name == "none" else int(corrector_steps)
+    counter = {"calls": 0}
+
+    def pc_sampler():
+        s = seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,)).item()) + counter["calls"]
+        counter["calls"] += 1
+        x, nfe = engine.pc_sample(y, noise, N=sde.N, corrector_steps=c_steps, snr=float(snr), t_eps=float(eps),
+                                  denoise=bool(denoise), seed=s)
+        return x, nfe
+
+    return pc_sampler

@@ -261,3 +261,68 @@ def test_dit_long_sequences(T, prec, tol):
     eng = make_engine(cfg, sd, precision=prec)
     assert rel_l2(eng.score(xt, t, mix), ref) < tol
     eng.close()
+
+
+# ------------------------------------------------------------------ facade (drop-in boundary)
+def _tiny_config(tmp_path):
+    import json
+    vae_json = {"model_type": "autoencoder", "sample_rate": 16000,
+                "model": {"encoder": {"type": "oobleck", "config": {"in_channels": 1, "channels": 32,
+                                                                     "c_mults": [1, 2, 4, 8, 16],
+                                                                     "strides": [2, 4, 4, 8, 8], "latent_dim": 128}},
+                          "decoder": {"type": "oobleck", "config": {"out_channels": 1, "channels": 32,
+                                                                     "c_mults": [1, 2, 4, 8, 16],
+                                                                     "strides": [2, 4, 4, 8, 8], "latent_dim": 64}},
+                          "bottleneck": {"type": "vae"}, "latent_dim": 64, "downsampling_ratio": 2048,
+                          "io_channels": 1}}
+    p = tmp_path / "vae.json"
+    p.write_text(json.dumps(vae_json))
+    return {"model": {"n_speakers": 2, "t_eps": 0.03,
+                      "score_model": {"_target_": "ditsep_amd.score_models.DiTScoreModel", "embed_dim": 128,
+                                      "depth": 2, "num_heads": 2},
+                      "vae": {"config_path": str(p), "ckpt_path": None, "trainable_vae": False},
+                      "sde": {"_target_": "sdes.sdes.OUVESDE", "theta": 1.5, "sigma_min": 0.96, "sigma_max": 10.0,
+                              "N": 4},
+                      "sampler": {"N": 4, "snr": 0.5, "corrector_steps": 1}}}
+
+
+def test_latentdiffsep_facade_matches_oracle(tmp_path):
+    from ditsep_amd import LatentDiffSep
+
+    vcfg = ovae.OobleckConfig(channels=32)
+    vsd = tiny_vae_weights(vcfg, 31)
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    model = LatentDiffSep(_tiny_config(tmp_path), precision="bf16x3")
+    sd = {"score_model." + k: v for k, v in dsd.items()}
+    sd.update({"vae." + k: v for k, v in vsd.items()})
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(33)
+    B, L = 3, 5000
+    mix = 0.3 * torch.randn((B, 1, L), generator=g)
+    ref = pipeline.separate(odit.DiTScore(dsd, dcfg), vsd, vcfg, mix, sampler.OUVE(N=4), 34, n_spkrs=2, eps=0.03,
+                            snr=0.5, corrector_steps=1, target_dim=L)
+    # separate(): the reference's one-call entry point
+    est, nfe = model.separate(mix, L, vae_noise=ref["vae_noise"], noise=ref["noise"])
+    assert nfe == 8 and rel_l2(est, ref["wav"]) < 1e-3
+    # the evaluate_latent.py sequence: encode -> get_pc_sampler -> sampler() -> decode
+    y, _ = model.encode(mix, None, vae_noise=ref["vae_noise"])
+    assert rel_l2(y, ref["y"]) < 1e-4
+    smp = model.get_pc_sampler("reverse_diffusion", "ald", y, N=4, denoise=True, corrector_steps=1, snr=0.5,
+                               noise=ref["noise"])
+    x, nfe = smp()
+    assert rel_l2(x, ref["x"]) < 1e-4
+    assert rel_l2(model.decode(x, L), ref["wav"]) < 1e-3
+    # minibatch chunking (diffsep_latent.py:432-469) gives the same samples
+    smp_mb = model.get_pc_sampler("reverse_diffusion", "ald", y, N=4, minibatch=2, corrector_steps=1, snr=0.5,
+                                  noise=ref["noise"])
+    xm, ns = smp_mb()
+    assert ns == [8, 8] and rel_l2(xm, ref["x"]) < 1e-4
+    # forward() is the score network
+    t = torch.tensor([0.5, 0.5, 0.5])
+    assert rel_l2(model.forward(ref["x"], t, ref["y"]), odit.DiTScore(dsd, dcfg)(ref["x"], t, ref["y"])) < 1e-4
+    with pytest.raises(ValueError):
+        model.get_pc_sampler("bogus", "ald", y)
+    with pytest.raises(NotImplementedError):
+        model.get_pc_sampler("euler_maruyama", "ald", y)
+    model.close()

@@ -1,0 +1,100 @@
+"""CPU-only: host-side mirror of the reference interface, C-ABI export surface, sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from ditsep_amd import distributed, native, sdes
+from ditsep_amd.registry import Registry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_semantics():
+    reg = Registry("Thing")
+
+    @reg.register("a")
+    class A:
+        pass
+
+    assert reg.get_by_name("a") is A and reg.get_all_names() == ["a"]
+    with pytest.raises(ValueError, match="Thing with name 'b' unknown"):
+        reg.get_by_name("b")
+    with pytest.warns(UserWarning, match="doubly registered"):
+        reg.register("a")(A)
+
+
+def test_registered_names_match_reference():
+    # reference src/sdes/predictors.py:39,55,69 and correctors.py:35,58,87,124
+    assert set(sdes.PredictorRegistry.get_all_names()) == {"euler_maruyama", "reverse_diffusion", "none"}
+    assert set(sdes.CorrectorRegistry.get_all_names()) == {"langevin", "ald", "ald2", "none"}
+    assert "ouve" in sdes.SDERegistry.get_all_names()
+
+
+def test_ouve_closed_forms_match_reference_tables(golden):
+    g = golden("sde_tables")
+    sde = sdes.OUVESDE(theta=1.5, sigma_min=0.96, sigma_max=10.0, N=30)
+    ts = torch.from_numpy(g["t_30"])
+    np.testing.assert_allclose(sde._std(ts).numpy(), g["std_30"], rtol=1e-6)
+    np.testing.assert_allclose(sde.sde(torch.zeros(30), ts, torch.zeros(30))[1].numpy(), g["g_30"], rtol=1e-6)
+    c = sde.copy()
+    c.N = 5
+    assert sde.N == 30 and c.theta == sde.theta and sde.T == 1
+
+
+def test_get_pc_sampler_error_behaviour():
+    sde = sdes.OUVESDE(1.5, 0.96, 10.0, N=3)
+    y = torch.zeros(1, 1, 64, 2)
+    with pytest.raises(ValueError):          # unknown registry name -> ValueError as the reference
+        sdes.get_pc_sampler("nope", "ald", sde, object(), y)
+    with pytest.raises(NotImplementedError):  # python score functions are not executed (no fallback)
+        sdes.get_pc_sampler("reverse_diffusion", "ald", sde, lambda x, t, y: x, y)
+
+
+def test_shard_bounds_cover_batch():
+    for B in (0, 1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_bounds(B, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a GPU-less host and exports every function
+    include/ditsep_hip.h declares (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, "include", "ditsep_hip.h")).read()
+    declared = set(re.findall(r"\b(dsn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    lib = native.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ditsep_hip.h but not exported"
+    assert declared == set(native.EXPORTS)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libditsep_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        native.load_library()
+
+
+def test_engine_requires_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="needs a ROCm GPU"):
+        native.Engine()
+
+
+def test_product_path_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under ditsep_amd/ may import it."""
+    pkg = os.path.join(ROOT, "ditsep_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
