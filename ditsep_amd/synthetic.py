@@ -264,3 +264,131 @@ def synthetic_sources(B: int, n: int, L: int, fs: int = 16000, seed: int = 1234)
             s = w * env
             out[b, k] = (0.3 * s / s.abs().max()).float()
     return out
+
+
+# ---------------------------------------------------------------------------
+# NCSN++ latent score network (the reference's wired-in score model)
+# ---------------------------------------------------------------------------
+@dataclass
+class NCSNppConfig:
+    """Defaults = src/config/latent_diffsep_ouve/model/default.yaml:16-28."""
+
+    n_src: int = 2
+    nf: int = 128
+    ch_mult: tuple = (1, 2, 2)
+    num_res_blocks: int = 2
+    attn_resolutions: tuple = (16,)
+    image_size: int = 64           # = latent dim (the "height" of the latent image)
+    max_latent_length: int = 4     # W is padded to a multiple of this
+    fourier_scale: float = 16.0
+
+    @property
+    def ch_in(self) -> int:
+        return self.n_src + 1
+
+    def layout(self):
+        """Module list in the reference's construction order (ncsnpp.py:107-309):
+        entries (index, kind, info)."""
+        nf, levels = self.nf, len(self.ch_mult)
+        res = [self.image_size // (2**i) for i in range(levels)]
+        mods = [(0, "fourier", {}), (1, "linear", dict(cin=2 * nf, cout=4 * nf)),
+                (2, "linear", dict(cin=4 * nf, cout=4 * nf)), (3, "conv3", dict(cin=self.ch_in, cout=nf))]
+        i = 4
+        hs_c = [nf]
+        in_ch = nf
+        for lv in range(levels):
+            for _ in range(self.num_res_blocks):
+                out_ch = nf * self.ch_mult[lv]
+                mods.append((i, "res", dict(cin=in_ch, cout=out_ch))); i += 1
+                in_ch = out_ch
+                if res[lv] in self.attn_resolutions:
+                    mods.append((i, "attn", dict(c=in_ch))); i += 1
+                hs_c.append(in_ch)
+            if lv != levels - 1:
+                mods.append((i, "res", dict(cin=in_ch, cout=in_ch, down=True))); i += 1
+                mods.append((i, "combine", dict(cin=self.ch_in, cout=in_ch))); i += 1
+                hs_c.append(in_ch)
+        mods.append((i, "res", dict(cin=in_ch, cout=in_ch))); i += 1
+        mods.append((i, "attn", dict(c=in_ch))); i += 1
+        mods.append((i, "res", dict(cin=in_ch, cout=in_ch))); i += 1
+        for lv in reversed(range(levels)):
+            for _ in range(self.num_res_blocks + 1):
+                out_ch = nf * self.ch_mult[lv]
+                mods.append((i, "res", dict(cin=in_ch + hs_c.pop(), cout=out_ch))); i += 1
+                in_ch = out_ch
+            if res[lv] in self.attn_resolutions:
+                mods.append((i, "attn", dict(c=in_ch))); i += 1
+            mods.append((i, "gn", dict(c=in_ch))); i += 1
+            mods.append((i, "conv3", dict(cin=in_ch, cout=self.ch_in))); i += 1
+            if lv != 0:
+                mods.append((i, "res", dict(cin=in_ch, cout=in_ch, up=True))); i += 1
+        assert not hs_c
+        return mods
+
+    @property
+    def n_modules(self) -> int:
+        return len(self.layout())
+
+    def reference_backbone_args(self) -> dict:
+        return dict(_target_="models.diffsep.ncsnpp.NCSNpp", nf=self.nf, ch_mult=list(self.ch_mult),
+                    num_res_blocks=self.num_res_blocks, attn_resolutions=list(self.attn_resolutions),
+                    resamp_with_conv=True, image_size=self.image_size, centered=True)
+
+
+def ncsnpp_param_shapes(cfg: NCSNppConfig, prefix: str = "backbone.") -> dict:
+    s = {}
+    temb = 4 * cfg.nf
+    for i, kind, a in cfg.layout():
+        p = f"{prefix}all_modules.{i}."
+        if kind == "fourier":
+            s[p + "W"] = (cfg.nf,)
+        elif kind == "linear":
+            s[p + "weight"], s[p + "bias"] = (a["cout"], a["cin"]), (a["cout"],)
+        elif kind == "conv3":
+            s[p + "weight"], s[p + "bias"] = (a["cout"], a["cin"], 3, 3), (a["cout"],)
+        elif kind == "gn":
+            s[p + "weight"], s[p + "bias"] = (a["c"],), (a["c"],)
+        elif kind == "combine":
+            s[p + "Conv_0.weight"], s[p + "Conv_0.bias"] = (a["cout"], a["cin"], 1, 1), (a["cout"],)
+        elif kind == "attn":
+            c = a["c"]
+            s[p + "GroupNorm_0.weight"], s[p + "GroupNorm_0.bias"] = (c,), (c,)
+            for k in range(4):
+                s[p + f"NIN_{k}.W"], s[p + f"NIN_{k}.b"] = (c, c), (c,)
+        elif kind == "res":
+            ci, co = a["cin"], a["cout"]
+            s[p + "GroupNorm_0.weight"], s[p + "GroupNorm_0.bias"] = (ci,), (ci,)
+            s[p + "Conv_0.weight"], s[p + "Conv_0.bias"] = (co, ci, 3, 3), (co,)
+            s[p + "Dense_0.weight"], s[p + "Dense_0.bias"] = (co, temb), (co,)
+            s[p + "GroupNorm_1.weight"], s[p + "GroupNorm_1.bias"] = (co,), (co,)
+            s[p + "Conv_1.weight"], s[p + "Conv_1.bias"] = (co, co, 3, 3), (co,)
+            if ci != co or a.get("up") or a.get("down"):
+                s[p + "Conv_2.weight"], s[p + "Conv_2.bias"] = (co, ci, 1, 1), (co,)
+    s[prefix + "output_layer.weight"] = (cfg.n_src, cfg.ch_in, 1, 1)
+    s[prefix + "output_layer.bias"] = (cfg.n_src,)
+    return s
+
+
+def random_ncsnpp_weights(cfg: NCSNppConfig, seed: int, out_gain: float = 1.0) -> dict:
+    """Seeded re-randomisation of every parameter (the reference zero-initialises Conv_1 / NIN_3 /
+    pyramid convs through init_scale=0 -> 1e-10): conv / linear weights ~ N(0, 1/fan_in),
+    norm gains 1 + 0.1 N, biases 0.1 N, Fourier W ~ N(0, scale^2); `out_gain` scales the 1x1 output layer."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in ncsnpp_param_shapes(cfg).items():
+        if name.endswith("all_modules.0.W"):
+            w = torch.randn(shape, generator=g) * cfg.fourier_scale
+        elif "GroupNorm" in name and name.endswith("weight") or (len(shape) == 1 and name.endswith("weight")):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias") or name.endswith(".b"):
+            w = 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".W"):           # NIN [in, out]
+            w = torch.randn(shape, generator=g) / math.sqrt(shape[0])
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            w = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        sd[name] = w
+    sd["backbone.output_layer.weight"] = sd["backbone.output_layer.weight"] * out_gain
+    return sd

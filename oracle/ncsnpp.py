@@ -1,0 +1,173 @@
+"""Oracle: NCSN++ latent score network as the reference wires it (CPU, fp32).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Functional restatement over an explicit state_dict (reference key names
+`backbone.all_modules.{i}.*`, `backbone.output_layer.*`) of
+  LatentScoreModelNCSNpp.forward           reference src/models/diffsep/score_models.py:140-186
+  NCSNpp.__init__ / forward                reference src/models/diffsep/ncsnpp.py:48-478
+  ResnetBlockBigGANpp                      reference ncsnpp_utils/layerspp.py:251-328
+  AttnBlockpp, Combine, GaussianFourierProjection   layerspp.py:37-97
+  NIN, ddpm_conv3x3/1x1                    ncsnpp_utils/layers.py:112-156,678-689
+  upsample_2d / downsample_2d (FIR [1,3,3,1]) ncsnpp_utils/up_or_down_sampling.py:192-273
+  upfirdn2d_native                         ncsnpp_utils/op/upfirdn2d.py:159-200
+for the configuration of src/config/latent_diffsep_ouve/model/default.yaml:16-28:
+biggan res-blocks, fir=True, skip_rescale, progressive='output_skip',
+progressive_input='input_skip' (combine 'sum'), fourier embedding (scale 16),
+scale_by_sigma, centered=True, dropout 0, attention where H == 16.
+
+The FIR resamplers are written in their closed separable form (per axis):
+  up  : out[2j] = .25 x[j-1] + .75 x[j] ; out[2j+1] = .75 x[j] + .25 x[j+1]
+  down: out[o]  = .125 x[2o-1] + .375 x[2o] + .375 x[2o+1] + .125 x[2o+2]   (zeros outside)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ditsep_amd.synthetic import NCSNppConfig, ncsnpp_param_shapes, random_ncsnpp_weights  # noqa: F401
+
+
+def _fir_axis(x: torch.Tensor, dim: int, up: bool) -> torch.Tensor:
+    n = x.shape[dim]
+    xp = F.pad(x.movedim(dim, -1), (2, 2)).movedim(-1, dim)      # two zeros either side
+
+    def sl(a, b, step=1):
+        idx = [slice(None)] * x.ndim
+        idx[dim] = slice(a, b, step)
+        return xp[tuple(idx)]
+
+    if up:
+        even = 0.25 * sl(1, 1 + n) + 0.75 * sl(2, 2 + n)         # x[j-1], x[j]
+        odd = 0.75 * sl(2, 2 + n) + 0.25 * sl(3, 3 + n)          # x[j], x[j+1]
+        out = torch.stack((even, odd), dim=dim + 1 if dim >= 0 else dim)
+        shape = list(x.shape)
+        shape[dim] = 2 * n
+        return out.reshape(shape)
+    m = n // 2
+    return (0.125 * sl(1, 1 + 2 * m, 2) + 0.375 * sl(2, 2 + 2 * m, 2)
+            + 0.375 * sl(3, 3 + 2 * m, 2) + 0.125 * sl(4, 4 + 2 * m, 2))
+
+
+def fir_up(x):
+    """[N,C,H,W] -> [N,C,2H,2W]  (upsample_2d(x, [1,3,3,1], factor=2))"""
+    return _fir_axis(_fir_axis(x, 2, True), 3, True)
+
+
+def fir_down(x):
+    """[N,C,H,W] -> [N,C,H/2,W/2]  (downsample_2d(x, [1,3,3,1], factor=2))"""
+    return _fir_axis(_fir_axis(x, 2, False), 3, False)
+
+
+def _gn(sd, p, x):
+    C = x.shape[1]
+    return F.group_norm(x, min(C // 4, 32), sd[p + "weight"], sd[p + "bias"], eps=1e-6)
+
+
+def _conv(sd, p, x, pad):
+    return F.conv2d(x, sd[p + "weight"], sd[p + "bias"], padding=pad)
+
+
+def _nin(sd, p, x):
+    return torch.einsum("bchw,co->bohw", x, sd[p + "W"]) + sd[p + "b"][None, :, None, None]
+
+
+def _resblock(sd, p, x, temb, up=False, down=False):
+    h = F.silu(_gn(sd, p + "GroupNorm_0.", x))
+    if up:
+        h, x = fir_up(h), fir_up(x)
+    elif down:
+        h, x = fir_down(h), fir_down(x)
+    h = _conv(sd, p + "Conv_0.", h, 1)
+    h = h + (F.silu(temb) @ sd[p + "Dense_0.weight"].t() + sd[p + "Dense_0.bias"])[:, :, None, None]
+    h = F.silu(_gn(sd, p + "GroupNorm_1.", h))
+    h = _conv(sd, p + "Conv_1.", h, 1)
+    if p + "Conv_2.weight" in sd:
+        x = _conv(sd, p + "Conv_2.", x, 0)
+    return (x + h) / np.sqrt(2.0)
+
+
+def _attn(sd, p, x):
+    B, C, H, W = x.shape
+    h = _gn(sd, p + "GroupNorm_0.", x)
+    q, k, v = (_nin(sd, p + f"NIN_{i}.", h) for i in range(3))
+    w = torch.einsum("bchw,bcij->bhwij", q, k) * (int(C) ** (-0.5))
+    w = F.softmax(w.reshape(B, H, W, H * W), dim=-1).reshape(B, H, W, H, W)
+    h = torch.einsum("bhwij,bcij->bchw", w, v)
+    h = _nin(sd, p + "NIN_3.", h)
+    return (x + h) / np.sqrt(2.0)
+
+
+def ncsnpp_forward(sd: dict, cfg: NCSNppConfig, x: torch.Tensor, t: torch.Tensor, prefix="backbone.") -> torch.Tensor:
+    """x [B, n+1, 64, W] (W multiple of 4), t [B] -> [B, n, 64, W]"""
+    mp = prefix + "all_modules."
+    levels = len(cfg.ch_mult)
+    res = [cfg.image_size // (2**i) for i in range(levels)]
+    m = 0
+    # time embedding
+    proj = torch.log(t)[:, None] * sd[mp + "0.W"][None, :] * 2 * np.pi
+    temb = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+    temb = temb @ sd[mp + "1.weight"].t() + sd[mp + "1.bias"]
+    temb = F.silu(temb) @ sd[mp + "2.weight"].t() + sd[mp + "2.bias"]
+    m = 3
+    pyr_in = x
+    hs = [_conv(sd, f"{mp}{m}.", x, 1)]
+    m += 1
+    for lv in range(levels):
+        for _ in range(cfg.num_res_blocks):
+            h = _resblock(sd, f"{mp}{m}.", hs[-1], temb)
+            m += 1
+            if res[lv] in cfg.attn_resolutions:
+                h = _attn(sd, f"{mp}{m}.", h)
+                m += 1
+            hs.append(h)
+        if lv != levels - 1:
+            h = _resblock(sd, f"{mp}{m}.", hs[-1], temb, down=True)
+            m += 1
+            pyr_in = fir_down(pyr_in)
+            h = _conv(sd, f"{mp}{m}.Conv_0.", pyr_in, 0) + h          # Combine, method 'sum'
+            m += 1
+            hs.append(h)
+    h = hs[-1]
+    h = _resblock(sd, f"{mp}{m}.", h, temb); m += 1
+    h = _attn(sd, f"{mp}{m}.", h); m += 1
+    h = _resblock(sd, f"{mp}{m}.", h, temb); m += 1
+    pyramid = None
+    for lv in reversed(range(levels)):
+        for _ in range(cfg.num_res_blocks + 1):
+            h = _resblock(sd, f"{mp}{m}.", torch.cat([h, hs.pop()], dim=1), temb)
+            m += 1
+        if res[lv] in cfg.attn_resolutions:
+            h = _attn(sd, f"{mp}{m}.", h)
+            m += 1
+        ph = F.silu(_gn(sd, f"{mp}{m}.", h)); m += 1
+        ph = _conv(sd, f"{mp}{m}.", ph, 1); m += 1
+        pyramid = ph if pyramid is None else fir_up(pyramid) + ph
+        if lv != 0:
+            h = _resblock(sd, f"{mp}{m}.", h, temb, up=True)
+            m += 1
+    assert not hs and m == cfg.n_modules, (m, cfg.n_modules)
+    h = pyramid / t[:, None, None, None]
+    return F.conv2d(h, sd[prefix + "output_layer.weight"], sd[prefix + "output_layer.bias"])
+
+
+class NCSNppScore:
+    """score_fn(xt, t, mix): cat on the source axis, pad W to a multiple of `max_latent_length`,
+    backbone, unpad (score_models.py:157-186)."""
+
+    def __init__(self, sd: dict, cfg: NCSNppConfig, prefix: str = "backbone."):
+        self.sd, self.cfg, self.prefix = sd, cfg, prefix
+
+    def __call__(self, xt, t, mix):
+        x = torch.cat((xt, mix), dim=1)
+        T = x.shape[-1]
+        rem = T % self.cfg.max_latent_length
+        pad = 0 if rem == 0 else self.cfg.max_latent_length - rem
+        if pad:
+            x = F.pad(x, (0, pad))
+        out = ncsnpp_forward(self.sd, self.cfg, x, t, self.prefix)
+        return out[..., :T] if pad else out

@@ -110,3 +110,36 @@ def test_e2e_tiny(golden):
     close(r["y"], g["y"])
     close(r["x"], g["x"], 5e-5)
     close(r["wav"], g["wav"], 5e-5)
+
+
+@pytest.mark.parametrize("tag", ["2spk", "3spk"])
+def test_ncsnpp_tiny(golden, tag):
+    from oracle import ncsnpp as oncs
+
+    g = golden(f"ncsnpp_tiny_{tag}")
+    cfg = oncs.NCSNppConfig(n_src=int(g["n_src"]), nf=int(g["nf"]))
+    sd = oncs.random_ncsnpp_weights(cfg, int(g["seed"]))
+    np.testing.assert_allclose(checksum(sd), g["wsum"], rtol=1e-9)
+    out = oncs.NCSNppScore(sd, cfg)(T(g["xt"]), T(g["t"]), T(g["mix"]))     # 3spk case has W=6 -> padded to 8
+    close(out, g["out"])
+
+
+def test_fir_resamplers_match_upfirdn_definition():
+    """Closed-form separable FIR == zero-insert / pad / correlate / decimate with [1,3,3,1]."""
+    from oracle.ncsnpp import fir_down, fir_up
+
+    x = torch.randn(2, 3, 8, 6, generator=torch.Generator().manual_seed(0))
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = torch.outer(k1, k1)
+    k2 = k2 / k2.sum()
+    # up: zero-insert x2, pad (2,1), true convolution with 4*k2
+    up = torch.zeros(2, 3, 16, 12)
+    up[:, :, ::2, ::2] = x
+    up = torch.nn.functional.pad(up, (2, 1, 2, 1))
+    w = (4 * k2).flip(0, 1)[None, None].repeat(3, 1, 1, 1)
+    ref_up = torch.nn.functional.conv2d(up, w, groups=3)
+    torch.testing.assert_close(fir_up(x), ref_up, atol=1e-6, rtol=1e-6)
+    dn = torch.nn.functional.pad(x, (1, 1, 1, 1))
+    w = k2.flip(0, 1)[None, None].repeat(3, 1, 1, 1)
+    ref_dn = torch.nn.functional.conv2d(dn, w, groups=3)[:, :, ::2, ::2]
+    torch.testing.assert_close(fir_down(x), ref_dn, atol=1e-6, rtol=1e-6)
