@@ -38,15 +38,20 @@ PRECISIONS = {"bf16": (native.PREC_BF16, "bf16 MFMA operands, fp32 accumulate"),
               "fp16x3": (native.PREC_FP16X3, "split-fp16 (hi,lo) MFMA operands x3, fp32 accumulate")}
 PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FS, SECONDS, N_STEPS, CORR, SNR, T_EPS = 16000, 4, 30, 1, 0.5, 0.03
-DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN = 0.002, 0.02, 0.08
+DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN, NCSN_OUT_GAIN = 0.002, 0.02, 0.08, 0.01
 
 
 def build_engine(device, precision, dcfg, vcfg, dsd, vsd):
-    eng = native.Engine(device=device, precision=precision, n_src=dcfg.n_src, latent_dim=dcfg.latent_dim,
-                        score_kind=native.SCORE_DIT, dit_embed_dim=dcfg.embed_dim, dit_depth=dcfg.depth,
-                        dit_heads=dcfg.num_heads, vae_channels=vcfg.channels, vae_c_mults=vcfg.c_mults,
-                        vae_strides=vcfg.strides, vae_enc_latent_dim=vcfg.enc_latent_dim,
-                        vae_use_snake=vcfg.use_snake, vae_final_tanh=vcfg.final_tanh)
+    score = dict(score_kind=native.SCORE_DIT, dit_embed_dim=dcfg.embed_dim, dit_depth=dcfg.depth,
+                 dit_heads=dcfg.num_heads, latent_dim=dcfg.latent_dim) if isinstance(dcfg, synthetic.DiTConfig) else \
+        dict(score_kind=native.SCORE_NCSNPP, ncsn_nf=dcfg.nf, ncsn_ch_mult=dcfg.ch_mult,
+             ncsn_num_res_blocks=dcfg.num_res_blocks, ncsn_attn_resolution=dcfg.attn_resolutions[0],
+             ncsn_image_size=dcfg.image_size, ncsn_max_latent_length=dcfg.max_latent_length,
+             latent_dim=dcfg.image_size)
+    eng = native.Engine(device=device, precision=precision, n_src=dcfg.n_src, vae_channels=vcfg.channels,
+                        vae_c_mults=vcfg.c_mults, vae_strides=vcfg.strides,
+                        vae_enc_latent_dim=vcfg.enc_latent_dim, vae_use_snake=vcfg.use_snake,
+                        vae_final_tanh=vcfg.final_tanh, **score)
     eng.load_state_dict(dsd, prefix="score_model.")
     eng.load_state_dict(vsd, prefix="vae.")
     eng.finalize()
@@ -57,6 +62,7 @@ def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
     """The CPU restatement of the reference path (oracle/, kind = "port") timed on
     this host: sampler + decode on `n_mix` mixtures of the same workload."""
     from oracle import dit as odit
+    from oracle import ncsnpp as oncs
     from oracle import oobleck as ovae
     from oracle import sampler as osmp
 
@@ -66,7 +72,7 @@ def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
     g = torch.Generator().manual_seed(99)
     y = torch.randn((n_mix, 1, vcfg.latent_dim, T), generator=g)
     noise = osmp.draw_noise(g, 1 + N_STEPS * (CORR + 1), (n_mix, dcfg.n_src, vcfg.latent_dim, T))
-    score = odit.DiTScore(dsd, dcfg)
+    score = odit.DiTScore(dsd, dcfg) if isinstance(dcfg, synthetic.DiTConfig) else oncs.NCSNppScore(dsd, dcfg)
     t0 = time.perf_counter()
     x, nfe = osmp.pc_sample(score, y, noise, osmp.OUVE(N=N_STEPS), eps=T_EPS, snr=SNR, corrector_steps=CORR,
                             denoise=True, n_spkrs=dcfg.n_src)
@@ -85,6 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="mixtures per GPU")
     ap.add_argument("--precision", choices=list(PRECISIONS), default="fp16")
     ap.add_argument("--alt", default="bf16x3,bf16", help="comma list of secondary precisions to also measure")
+    ap.add_argument("--score", choices=["dit", "ncsnpp"], default="dit",
+                    help="dit: the north-star DiT score network (ditsep.json dims); ncsnpp: the NCSN++ the reference wires in")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary-precision measurement")
@@ -102,9 +110,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    dcfg = synthetic.DiTConfig()                       # ditsep.json dims: 1024 x 24 layers x 16 heads
     vcfg = synthetic.OobleckConfig()                   # oobleck_finetune.json
-    dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=DIT_OUT_GAIN, skip_gain=DIT_SKIP_GAIN)
+    if args.score == "dit":
+        dcfg = synthetic.DiTConfig()                   # ditsep.json dims: 1024 x 24 layers x 16 heads
+        dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=DIT_OUT_GAIN, skip_gain=DIT_SKIP_GAIN)
+        score_desc = "DiT 1024x24x16 (ditsep.json dims) via (xt,t,mix) adapter"
+    else:
+        dcfg = synthetic.NCSNppConfig()                # latent_diffsep_ouve/model/default.yaml:16-28
+        dsd = synthetic.random_ncsnpp_weights(dcfg, 1, out_gain=NCSN_OUT_GAIN)
+        score_desc = "NCSN++ latent U-Net nf=128 ch_mult (1,2,2) (LatentScoreModelNCSNpp, as wired in the reference)"
     vsd = synthetic.vae_weights(vcfg, 2, dec_in_gain=DEC_IN_GAIN)
     prec = PRECISIONS[args.precision][0]
     log("weights generated")
@@ -177,7 +191,7 @@ def main():
         "config": {"workload": "C2 Libri2Mix-shape: 2-spk 16 kHz 4 s mixtures, N=30 PC sampler "
                                "(reverse_diffusion + ald, 1 corrector step, 60 NFE) + Oobleck decode, "
                                f"batch={B} per GPU",
-                   "score_net": "DiT 1024x24x16 (ditsep.json dims) via (xt,t,mix) adapter",
+                   "score_net": score_desc,
                    "vae": "Oobleck decoder 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
                    "global_batch": world * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
                    "parallelism": f"dp{world}: batch sharded, one RCCL gather of waveforms per step"},

@@ -22,28 +22,29 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <int P, int F16, int NKT>
+template <int P, int F16, int NKT, int DH>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __restrict__ qkv, long ps,
                                                             op16_t* __restrict__ out, long out_ps, int S, int H) {
-  extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][nkt*16][64]
+  extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][nkt*16][DH]
   const int lane = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int D = H * 64;
+  const int D = H * DH;
   const long rs = 3L * D;  // token row stride
-  const op16_t* qb = qkv + (long)b * S * rs + h * 64;
+  const op16_t* qb = qkv + (long)b * S * rs + h * DH;
   const op16_t* kb = qb + D;
   const op16_t* vb = qb + 2 * D;
   const int nkt = (S + 15) >> 4;
   const int vrows = nkt * 16;
 
-  // stage V (zero beyond S) -- 8 lanes x 16 B per token row
+  // stage V (zero beyond S) -- DH/8 lanes x 16 B per token row
+  constexpr int CPRV = DH / 8;
   const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int idx = lane; idx < vrows * 8; idx += 64) {
-    const int row = idx >> 3, c = idx & 7;
+  for (int idx = lane; idx < vrows * CPRV; idx += 64) {
+    const int row = idx / CPRV, c = idx % CPRV;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const op16x8 v = row < S ? *reinterpret_cast<const op16x8*>(vb + p * ps + row * rs + c * 8) : zero8;
-      *reinterpret_cast<op16x8*>(vlds + ((long)p * vrows + row) * 64 + c * 8) = v;
+      *reinterpret_cast<op16x8*>(vlds + ((long)p * vrows + row) * DH + c * 8) = v;
     }
   }
   __syncthreads();
@@ -54,11 +55,12 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   for (int qt = 0; qt < nkt; ++qt) {
     // ---- scores^T = K Q^T -------------------------------------------------
     const int qrow = min(qt * 16 + r16, S - 1);
-    op16x8 fq[P][2];
+    constexpr int KSD = DH / 32;
+    op16x8 fq[P][KSD];
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KSD; ++ks)
         fq[p][ks] = *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
     f32x4 sc[NKT];
 #pragma unroll
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
       if (kt < nkt) {
         const int krow = min(kt * 16 + r16, S - 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSD; ++ks) {
           op16x8 fk[P];
 #pragma unroll
           for (int p = 0; p < P; ++p)
@@ -108,9 +110,10 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
     lsum += __shfl_xor(lsum, 32, 64);
 
     // ---- O^T = V^T P^T ----------------------------------------------------------
-    f32x4 oacc[4];
+    constexpr int NDT = DH / 16;
+    f32x4 oacc[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NKT / 2; ++u) {
       if (2 * u < nkt) {
@@ -125,17 +128,17 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
         }
         const bool second = 2 * u + 1 < nkt;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
           op16x8 fv[P];
 #pragma unroll
           for (int p = 0; p < P; ++p) {
-            const op16_t* base = vlds + (long)p * vrows * 64 + dt * 16 + 4 * tp;
+            const op16_t* base = vlds + (long)p * vrows * DH + dt * 16 + 4 * tp;
             const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(base + ((2 * u) * 16 + 4 * g + tq) * 64));
+                (__attribute__((address_space(3))) s16x4*)(base + ((2 * u) * 16 + 4 * g + tq) * DH));
             // rows of a tile past the sequence end are zero-filled in LDS; clamp the address only
             const int t1 = second ? 2 * u + 1 : 2 * u;
             s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(base + (t1 * 16 + 4 * g + tq) * 64));
+                (__attribute__((address_space(3))) s16x4*)(base + (t1 * 16 + 4 * g + tq) * DH));
             if (!second) hi4 = s16x4{0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
     const int qi = qt * 16 + r16;
     if (qi < S) {
       const float inv = 1.f / lsum;
-      const long obase = ((long)b * S + qi) * D + h * 64 + 4 * g;
+      const long obase = ((long)b * S + qi) * D + h * DH + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < NDT; ++dt) {
         op16x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -173,30 +176,42 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   }
 }
 
-template <int P, int F16>
+template <int P, int F16, int DH>
 void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S, int H, hipStream_t st) {
   const int nkt = (S + 15) / 16;
-  const size_t sm = (size_t)P * nkt * 16 * 64 * sizeof(op16_t);
+  const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);
   if (nkt <= 4) {
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S, H);
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S,
+                       H);
   } else {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<P, F16, 16>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<P, F16, 16, DH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S, H);
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S,
+                       H);
   }
+}
+
+template <int DH>
+void launch_dh(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, hipStream_t st) {
+  const int P = PL_COUNT(pl), f16 = PL_F16(pl);
+  if (P == 1 && !f16) launch_t<1, 0, DH>(qkv, ps, out, out_ps, B, S, H, st);
+  else if (P == 2 && !f16) launch_t<2, 0, DH>(qkv, ps, out, out_ps, B, S, H, st);
+  else if (P == 1) launch_t<1, 1, DH>(qkv, ps, out, out_ps, B, S, H, st);
+  else launch_t<2, 1, DH>(qkv, ps, out, out_ps, B, S, H, st);
 }
 
 }  // namespace
 
-void launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H,
-                           hipStream_t st) {
-  const int P = PL_COUNT(pl), f16 = PL_F16(pl);
-  if (P == 1 && !f16) launch_t<1, 0>(qkv, ps, out, out_ps, B, S, H, st);
-  else if (P == 2 && !f16) launch_t<2, 0>(qkv, ps, out, out_ps, B, S, H, st);
-  else if (P == 1) launch_t<1, 1>(qkv, ps, out, out_ps, B, S, H, st);
-  else launch_t<2, 1>(qkv, ps, out, out_ps, B, S, H, st);
+// dh = head width (64: DiT; 64/128/256: the single-head NCSN++ attention blocks)
+int launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, int dh,
+                          hipStream_t st) {
+  if (dh == 64) launch_dh<64>(qkv, ps, out, out_ps, pl, B, S, H, st);
+  else if (dh == 128) launch_dh<128>(qkv, ps, out, out_ps, pl, B, S, H, st);
+  else if (dh == 256) launch_dh<256>(qkv, ps, out, out_ps, pl, B, S, H, st);
+  else return -1;
+  return 0;
 }

@@ -356,6 +356,7 @@ struct dsn_ctx {
         L.ff2 = pack_linear(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
       }
     }
+    if (cfg.score_kind == DSN_SCORE_NCSNPP) finalize_ncsnpp(st);
     const int nb = cfg.vae_n_blocks;
     const int ch = cfg.vae_channels;
     std::vector<int> mult(nb + 1, 1);
@@ -469,10 +470,14 @@ struct dsn_ctx {
     d.tap_dil = 1;
     d.in_pad = 0;
     d.in_bstride = (long)Lin * w.Cin;
+    d.in_row_elems = w.Cin;
     d.out_bstride = (long)rows_per_b * w.N;
     d.out_row_elems = w.N;
     d.out_off = 0;
     d.out_limit = d.out_bstride;
+    d.resid_bstride = d.out_bstride;
+    d.resid_row_elems = d.out_row_elems;
+    d.resid_off = d.out_off;
     d.bias = w.bias;
     d.bias_mod = w.bias_mod;
     d.out_scale = 1.f;
@@ -589,7 +594,7 @@ struct dsn_ctx {
         d.q_scale = 0.125f;
         run(d, st);
       }
-      launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, st);
+      launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         d.ksplit = pick_ksplit(d);
@@ -657,9 +662,12 @@ struct dsn_ctx {
     return SC;
   }
 
+#include "engine_ncsnpp.inc"
+
   float* score_tokens(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
     if (!finalized) fail(DSN_ESTATE, "weights not finalized");
     if (cfg.score_kind == DSN_SCORE_DIT) return dit_forward(xt, t, mix, B, T, st);
+    if (cfg.score_kind == DSN_SCORE_NCSNPP) return ncsnpp_forward(xt, t, mix, B, T, st);
     fail(DSN_ESTATE, "no score network configured (score_kind=%d)", cfg.score_kind);
   }
 
@@ -1133,6 +1141,17 @@ int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const f
   if ((rc = dsn_pc_sample(ctx, y, noise, seed + 1, x, B, T, N, corrector_steps, snr, t_eps, denoise, nfe_out, stream)))
     return rc;
   return dsn_decode(ctx, x, wav, B, T, target_len > 0 ? target_len : L, stream);
+}
+
+// Development hook: copy `count` floats of the named workspace buffer to host memory.
+int dsn_debug_read(dsn_ctx* ctx, const char* name, float* host, int64_t count) {
+  return guarded(ctx, [&] {
+    auto it = ctx->ws.find(name);
+    if (it == ctx->ws.end()) fail(DSN_EINVAL, "no workspace buffer '%s'", name);
+    if ((size_t)count * sizeof(float) > it->second.second) fail(DSN_EINVAL, "buffer '%s' smaller than request", name);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, it->second.first, sizeof(float) * count, hipMemcpyDeviceToHost));
+  });
 }
 
 int dsn_enable_graphs(dsn_ctx* ctx, int enable) {

@@ -23,13 +23,20 @@ struct GemmDesc {
   long w_ps;  // plane stride of W
   int M, N, Cin, taps;
   int rows_per_b, Lin, in_stride, tap_dil, in_pad;
-  long in_bstride;  // elements per batch item of A (normally Lin*Cin)
+  long in_bstride;  // elements per batch item of A (normally Lin*in_row_elems)
+  int in_row_elems; // elements between consecutive input rows (Cin, or more for a channel slice of a wider tensor)
+  // 2-D mode (img_w > 0): rows are (y, x) of an img_h x img_w image, taps = 9 -> (dy, dx) in {-1,0,1}^2
+  int img_h, img_w;
   long out_bstride;
   int out_row_elems, out_off;
   long out_limit;
   const float* bias;  // [bias_mod] or null; indexed n % bias_mod (packed order when swiglu)
   int bias_mod;
-  const float* resid;  // fp32, same addressing as out, or null
+  const float* resid;  // fp32 or null; addressed b*resid_bstride + j*resid_row_elems + resid_off + n
+  long resid_bstride;
+  int resid_row_elems, resid_off;
+  const float* bbias;  // per-(batch item, channel) bias [B][bbias_stride] or null (time-embedding bias)
+  int bbias_stride;
   float* out_f32;      // or null
   int f32_op;          // DSN_F32_*
   float out_scale;     // applied after bias + residual

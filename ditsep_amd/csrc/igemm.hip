@@ -73,10 +73,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
           const f32x4 x0 = acc[0][tm], x1 = acc[1][tm];
           acc[0][tm] = x0 * c0 - x1 * s0;
           acc[1][tm] = x1 * c1 + x0 * s1;
-          if (section == 0) {
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tn][tm] *= d.q_scale;
-          }
         }
       }
 #pragma unroll
@@ -88,7 +84,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
         const long off = row_abs + n;
         f32x4 v = acc[tn][tm];
         if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
-        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + off);
+        if (d.qkv_D > 0 && n < d.qkv_D) v *= d.q_scale;  // fused q|k|v projection: q (bias included) pre-scaled
+        if (d.bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
+        if (d.resid)
+          v += *reinterpret_cast<const f32x4*>(d.resid + (long)b * d.resid_bstride + (long)j * d.resid_row_elems +
+                                               d.resid_off + n);
         v *= d.out_scale;
         if (d.out_f32) {
           f32x4 o = v;
@@ -208,9 +208,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const GemmDesc d) {
     const int kc = kt - tap * kc_per_tap;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = a_js[i] + tap * d.tap_dil;
-      const bool ok = a_ok[i] && r >= 0 && r < d.Lin;
-      const long aoff = a_base[i] + (long)r * d.Cin + kc * BK;
+      int r = a_js[i] + tap * d.tap_dil;
+      bool ok = a_ok[i] && r >= 0 && r < d.Lin;
+      if (d.img_w > 0) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int y = a_js[i] / d.img_w, x = a_js[i] - y * d.img_w;
+        ok = a_ok[i] && (unsigned)(y + dy) < (unsigned)d.img_h && (unsigned)(x + dx) < (unsigned)d.img_w;
+        r = a_js[i] + dy * d.img_w + dx;
+      }
+      const long aoff = a_base[i] + (long)r * d.in_row_elems + kc * BK;
       const long woff = w_base[i] + (long)tap * d.Cin + kc * BK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -368,7 +374,8 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   int r_js[GPW], r_dil[GPW];
   unsigned r_lim[GPW];
   long r_rowel[GPW], r_tapel[GPW];
-  bool r_ok[GPW];
+  bool r_ok[GPW], r_2d[GPW];
+  int r_y[GPW], r_x[GPW];
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave * GPW + gi;
@@ -385,8 +392,11 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     r_js[gi] = is_a ? j * d.in_stride - d.in_pad : 0;
     r_dil[gi] = is_a ? d.tap_dil : 0;
     r_lim[gi] = is_a ? (unsigned)d.Lin : 1u;
-    r_rowel[gi] = is_a ? d.Cin : 0;
+    r_rowel[gi] = is_a ? d.in_row_elems : 0;
     r_tapel[gi] = is_a ? 0 : d.Cin;
+    r_y[gi] = (d.img_w > 0 && is_a) ? j / d.img_w : 0;
+    r_x[gi] = (d.img_w > 0 && is_a) ? j - r_y[gi] * d.img_w : 0;
+    r_2d[gi] = d.img_w > 0 && is_a;
   }
   const op16_t* zsrc = zero_page + cpos * 8;
 
@@ -396,8 +406,13 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     op16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * RPG * TBK;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
-      const int r = r_js[gi] + tap * r_dil[gi];
-      const bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
+      int r = r_js[gi] + tap * r_dil[gi];
+      bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
+      if (r_2d[gi]) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        ok = r_ok[gi] && (unsigned)(r_y[gi] + dy) < (unsigned)d.img_h && (unsigned)(r_x[gi] + dx) < (unsigned)d.img_w;
+        r = r_js[gi] + dy * d.img_w + dx;
+      }
       const op16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * TBK;
 #pragma unroll
       for (int p = 0; p < P; ++p) {

@@ -40,8 +40,8 @@ void launch_attention(const float* qkv, const float* rope_cos, const float* rope
                       long ps, int planes, int B, int S, int H, int dh, hipStream_t s);
 // MFMA attention over operand planes q|k|v [B*S][3*H*64] written by the fused QKV epilogue
 // (attention.hip); S <= 256.
-void launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H,
-                           hipStream_t s);
+int launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, int dh,
+                          hipStream_t s);   // dh in {64,128,256}; returns -1 for an unsupported head width
 void launch_rope_tables(float* cos_t, float* sin_t, int S, int rot, hipStream_t s);
 
 // ---- Oobleck edges -------------------------------------------------------------
@@ -60,7 +60,9 @@ void launch_vae_sample(const float* enc_tok, const float* noise, float* y, int S
 void launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, hipStream_t s);
 
 // ---- weight packing ---------------------------------------------------------------
-enum { PACK_LINEAR = 0, PACK_LINEAR_SWIGLU = 1, PACK_CONV = 2, PACK_CONVT = 3 };
+enum { PACK_LINEAR = 0, PACK_LINEAR_SWIGLU = 1, PACK_CONV = 2, PACK_CONVT = 3, PACK_CONV2D = 4, PACK_NIN = 5 };
+// PACK_CONV2D: src [Cout][Cin][taps] (taps = kw: 9 for 3x3 row-major (ky,kx), 1 for 1x1) -> dst [N][taps*Cin_pad],
+//   Cin_pad = `stride`, zero where ci >= Cin or n >= Cout.   PACK_NIN: src [Cin][Cout] -> dst [Cout][Cin].
 // per-row scale g / ||v|| for old-style weight norm (norm over all dims but 0); v [R][inner]
 void launch_wn_scale(const float* v, const float* g, float* scale, int R, long inner, hipStream_t s);
 // generic gather into packed [N][K] planes; see kernels.hip for the index maps
@@ -70,3 +72,20 @@ void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t s)
 // snake parameters: alpha -> exp(alpha), beta -> 1/(exp(beta)+1e-9)
 void launch_snake_params(const float* alpha, const float* beta, float* a_out, float* ib_out, int C,
                          hipStream_t s);
+
+// ---- NCSN++ (ncsn_kernels.hip): channels-last images, row = (item, y, x) -------------------------
+// Views: x + item*bstride + row*rstride + channel (rstride >= C lets a kernel read a channel slice
+// of a wider concat buffer).
+void launch_ncsn_pack(const float* xt, const float* mix, int B, int n, int H, int T, int Wp, int Cp, float* of,
+                      op16_t* op, long ps, int planes, hipStream_t s);
+void launch_gn_stats(const float* x, long bstride, int rstride, int C, int G, int B, int HW, float* stats,
+                     hipStream_t s);   // stats [B][G][2] = (sum, sum of squares); zeroed inside
+void launch_gn_apply(const float* x, long bstride, int rstride, int C, int G, int B, int HW, const float* stats,
+                     const float* gamma, const float* beta, float eps, int silu, float* of, op16_t* op, long ps,
+                     int planes, hipStream_t s);
+void launch_fir2d(const float* x, long bstride, int rstride, int C, int B, int H, int W, int up, const float* add,
+                  float* of, op16_t* op, long ps, int planes, hipStream_t s);
+void launch_ncsn_fourier(const float* t, const float* w, int B, int nf, op16_t* out, long ps, int planes,
+                         hipStream_t s);
+void launch_ncsn_output(const float* pyr, int Cp, const float* t, const float* w, const float* bias, int cin, int n,
+                        int B, int H, int T, int Wp, float* score, hipStream_t s);

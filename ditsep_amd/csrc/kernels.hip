@@ -521,6 +521,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const float* _
       const int tap = k / Cin, ci = k - tap * Cin;
       v = src[((long)n * Cin + ci) * kw + tap];
       if (scale) v *= scale[n];
+    } else if (mode == PACK_CONV2D) {
+      const int cpad = stride;
+      const int tap = k / cpad, ci = k - tap * cpad;
+      v = (n < Cout && ci < Cin) ? src[((long)n * Cin + ci) * kw + tap] : 0.f;
+    } else if (mode == PACK_NIN) {
+      v = src[(long)k * N + n];
     } else {  // PACK_CONVT: n = phase*Cout + co ; k = tap*Cin + ci ; kernel index = phase + tap*stride
       const int p = n / Cout, co = n - p * Cout;
       const int tap = k / Cin, ci = k - tap * Cin;

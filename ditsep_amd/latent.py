@@ -76,7 +76,15 @@ class LatentDiffSep:
             args.update(score_kind=native.SCORE_DIT, dit_embed_dim=int(_get(sm, "embed_dim", 1024)),
                         dit_depth=int(_get(sm, "depth", 24)), dit_heads=int(_get(sm, "num_heads", 16)))
         elif target.endswith("LatentScoreModelNCSNpp"):
-            raise NotImplementedError("NCSN++ score network: native kernels not available in this build")
+            ba = _get(sm, "backbone_args")
+            attn = tuple(_get(ba, "attn_resolutions", (16,)))
+            if len(attn) != 1:
+                raise NotImplementedError("NCSN++: exactly one attention resolution is implemented natively")
+            args.update(score_kind=native.SCORE_NCSNPP, ncsn_nf=int(_get(ba, "nf", 128)),
+                        ncsn_ch_mult=tuple(_get(ba, "ch_mult", (1, 2, 2))),
+                        ncsn_num_res_blocks=int(_get(ba, "num_res_blocks", 2)), ncsn_attn_resolution=int(attn[0]),
+                        ncsn_image_size=int(_get(ba, "image_size", 64)),
+                        ncsn_max_latent_length=int(_get(sm, "max_latent_length", 16)))
         elif target == "":
             args.update(score_kind=native.SCORE_NONE)
         else:

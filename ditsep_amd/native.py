@@ -27,7 +27,7 @@ EXPORTS = [
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
-    "dsn_bench_igemm",
+    "dsn_bench_igemm", "dsn_debug_read",
 ]
 
 
@@ -36,6 +36,9 @@ class DsnConfig(C.Structure):
         ("device", C.c_int32), ("precision", C.c_int32), ("n_src", C.c_int32), ("latent_dim", C.c_int32),
         ("score_kind", C.c_int32), ("dit_embed_dim", C.c_int32), ("dit_depth", C.c_int32),
         ("dit_heads", C.c_int32),
+        ("ncsn_nf", C.c_int32), ("ncsn_n_levels", C.c_int32), ("ncsn_ch_mult", C.c_int32 * 4),
+        ("ncsn_num_res_blocks", C.c_int32), ("ncsn_attn_resolution", C.c_int32), ("ncsn_image_size", C.c_int32),
+        ("ncsn_max_latent_length", C.c_int32),
         ("vae_channels", C.c_int32), ("vae_n_blocks", C.c_int32),
         ("vae_c_mults", C.c_int32 * MAX_VAE_BLOCKS), ("vae_strides", C.c_int32 * MAX_VAE_BLOCKS),
         ("vae_enc_latent_dim", C.c_int32), ("vae_use_snake", C.c_int32), ("vae_final_tanh", C.c_int32),
@@ -81,6 +84,7 @@ def load_library() -> C.CDLL:
     lib.dsn_profile_begin.argtypes = [vp]
     lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.dsn_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
     lib.dsn_bench_igemm.argtypes = [vp] + [ci] * 10 + [C.POINTER(C.c_double)]
     for name in EXPORTS:
         getattr(lib, name)      # every symbol include/ditsep_hip.h declares must resolve
@@ -101,7 +105,9 @@ class Engine:
 
     def __init__(self, *, device: int = 0, precision: int = PREC_BF16X3, n_src: int = 2, latent_dim: int = 64,
                  score_kind: int = SCORE_DIT, dit_embed_dim: int = 1024, dit_depth: int = 24,
-                 dit_heads: int = 16, vae_channels: int = 128, vae_c_mults=(1, 2, 4, 8, 16),
+                 dit_heads: int = 16, ncsn_nf: int = 128, ncsn_ch_mult=(1, 2, 2), ncsn_num_res_blocks: int = 2,
+                 ncsn_attn_resolution: int = 16, ncsn_image_size: int = 64, ncsn_max_latent_length: int = 4,
+                 vae_channels: int = 128, vae_c_mults=(1, 2, 4, 8, 16),
                  vae_strides=(2, 4, 4, 8, 8), vae_enc_latent_dim: int = 128, vae_use_snake: bool = False,
                  vae_final_tanh: bool = True, vae_has_encoder: bool = True, vae_has_decoder: bool = True,
                  sde_theta: float = 1.5, sde_sigma_min: float = 0.96, sde_sigma_max: float = 10.0):
@@ -112,6 +118,11 @@ class Engine:
         cfg.device, cfg.precision, cfg.n_src, cfg.latent_dim = device, precision, n_src, latent_dim
         cfg.score_kind = score_kind
         cfg.dit_embed_dim, cfg.dit_depth, cfg.dit_heads = dit_embed_dim, dit_depth, dit_heads
+        cfg.ncsn_nf, cfg.ncsn_n_levels = ncsn_nf, len(ncsn_ch_mult)
+        for i, m in enumerate(ncsn_ch_mult):
+            cfg.ncsn_ch_mult[i] = int(m)
+        cfg.ncsn_num_res_blocks, cfg.ncsn_attn_resolution = ncsn_num_res_blocks, ncsn_attn_resolution
+        cfg.ncsn_image_size, cfg.ncsn_max_latent_length = ncsn_image_size, ncsn_max_latent_length
         cfg.vae_channels, cfg.vae_n_blocks = vae_channels, len(vae_c_mults)
         assert len(vae_c_mults) == len(vae_strides) <= MAX_VAE_BLOCKS
         for i, (m, s) in enumerate(zip(vae_c_mults, vae_strides)):
@@ -247,6 +258,12 @@ class Engine:
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.dsn_profile_end(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)), "dsn_profile_end")
         return {"gemm_ms": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
+
+    def debug_read(self, name: str, shape):
+        out = torch.empty(shape, dtype=torch.float32)
+        self._check(self.lib.dsn_debug_read(self.ctx, name.encode(), C.c_void_p(out.data_ptr()), out.numel()),
+                    f"dsn_debug_read({name})")
+        return out
 
     def bench_igemm(self, B, Lin, Cin, N, taps=1, tap_dil=1, in_pad=0, ksplit=1, variant=2, iters=10):
         ms = C.c_double()

@@ -50,6 +50,10 @@ typedef struct dsn_config {
   /* score network */
   int32_t score_kind;  /* DSN_SCORE_*                                              */
   int32_t dit_embed_dim, dit_depth, dit_heads;
+  /* NCSN++ latent score network (config.model.score_model.backbone_args, default.yaml:16-28) */
+  int32_t ncsn_nf, ncsn_n_levels;
+  int32_t ncsn_ch_mult[4];
+  int32_t ncsn_num_res_blocks, ncsn_attn_resolution, ncsn_image_size, ncsn_max_latent_length;
   /* Oobleck VAE (oobleck_finetune.json keys) */
   int32_t vae_channels;
   int32_t vae_n_blocks;                       /* len(c_mults) == len(strides)      */
@@ -128,6 +132,8 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N,
                    int taps, int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream);
 
+/* Development hook: copy `count` floats of a named workspace buffer to host memory. */
+int dsn_debug_read(dsn_ctx* ctx, const char* name, float* host, int64_t count);
 /* Development hook: average milliseconds of `iters` launches of the implicit-GEMM kernel on random
  * operands of the given contraction (variant 1 = register-staged core, 2 = glds-ring core). */
 int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int tap_dil, int in_pad, int ksplit,

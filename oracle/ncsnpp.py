@@ -102,7 +102,7 @@ def _attn(sd, p, x):
     return (x + h) / np.sqrt(2.0)
 
 
-def ncsnpp_forward(sd: dict, cfg: NCSNppConfig, x: torch.Tensor, t: torch.Tensor, prefix="backbone.") -> torch.Tensor:
+def ncsnpp_forward(sd: dict, cfg: NCSNppConfig, x: torch.Tensor, t: torch.Tensor, prefix="backbone.", rec=None) -> torch.Tensor:
     """x [B, n+1, 64, W] (W multiple of 4), t [B] -> [B, n, 64, W]"""
     mp = prefix + "all_modules."
     levels = len(cfg.ch_mult)
@@ -132,6 +132,9 @@ def ncsnpp_forward(sd: dict, cfg: NCSNppConfig, x: torch.Tensor, t: torch.Tensor
             h = _conv(sd, f"{mp}{m}.Conv_0.", pyr_in, 0) + h          # Combine, method 'sum'
             m += 1
             hs.append(h)
+    if rec is not None:
+        rec["hs"] = [a.clone() for a in hs]
+        rec["temb"] = temb
     h = hs[-1]
     h = _resblock(sd, f"{mp}{m}.", h, temb); m += 1
     h = _attn(sd, f"{mp}{m}.", h); m += 1
@@ -150,6 +153,8 @@ def ncsnpp_forward(sd: dict, cfg: NCSNppConfig, x: torch.Tensor, t: torch.Tensor
         if lv != 0:
             h = _resblock(sd, f"{mp}{m}.", h, temb, up=True)
             m += 1
+    if rec is not None:
+        rec["pyramid"] = pyramid
     assert not hs and m == cfg.n_modules, (m, cfg.n_modules)
     h = pyramid / t[:, None, None, None]
     return F.conv2d(h, sd[prefix + "output_layer.weight"], sd[prefix + "output_layer.bias"])

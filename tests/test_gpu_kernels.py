@@ -326,3 +326,81 @@ def test_latentdiffsep_facade_matches_oracle(tmp_path):
     with pytest.raises(NotImplementedError):
         model.get_pc_sampler("euler_maruyama", "ald", y)
     model.close()
+
+
+# ------------------------------------------------------------------ NCSN++ (the wired-in score net)
+@pytest.mark.parametrize("tag", ["2spk", "3spk"])
+@pytest.mark.parametrize("prec,tol", [(X3, 2e-4), (FP16, 5e-3)])
+def test_ncsnpp_tiny_vs_golden(golden, tag, prec, tol):
+    from oracle import ncsnpp as oncs
+
+    g = golden(f"ncsnpp_tiny_{tag}")
+    cfg = oncs.NCSNppConfig(n_src=int(g["n_src"]), nf=int(g["nf"]))
+    sd = oncs.random_ncsnpp_weights(cfg, int(g["seed"]))
+    eng = make_engine(ncfg=cfg, nsd=sd, precision=prec)
+    out = eng.score(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]), torch.from_numpy(g["mix"]))
+    assert rel_l2(out, torch.from_numpy(g["out"])) < tol
+    eng.close()
+
+
+def test_ncsnpp_full_size_vs_oracle():
+    """default.yaml dimensions (nf=128, ch_mult [1,2,2], attention at H=16), Libri2Mix latent shape T=32."""
+    from oracle import ncsnpp as oncs
+
+    torch.set_num_threads(16)
+    cfg = oncs.NCSNppConfig()
+    sd = oncs.random_ncsnpp_weights(cfg, 7)
+    g = torch.Generator().manual_seed(8)
+    B, T = 2, 32
+    xt = 3.0 * torch.randn((B, 2, 64, T), generator=g)
+    mix = torch.randn((B, 1, 64, T), generator=g)
+    t = torch.tensor([0.9, 0.05])
+    ref = oncs.NCSNppScore(sd, cfg)(xt, t, mix)
+    eng = make_engine(ncfg=cfg, nsd=sd, precision=X3)
+    assert rel_l2(eng.score(xt, t, mix), ref) < 2e-4
+    eng.close()
+
+
+def test_ncsnpp_sampler_vs_oracle():
+    from oracle import ncsnpp as oncs
+
+    cfg = oncs.NCSNppConfig(nf=32)
+    sd = oncs.random_ncsnpp_weights(cfg, 9, out_gain=0.02)
+    eng = make_engine(ncfg=cfg, nsd=sd, precision=X3)
+    g = torch.Generator().manual_seed(10)
+    y = torch.randn((2, 1, 64, 6), generator=g)               # T=6 -> padded to 8 inside the score net
+    noise = sampler.draw_noise(11, 1 + 4 * 2, (2, 2, 64, 6))
+    ref, nfe = sampler.pc_sample(oncs.NCSNppScore(sd, cfg), y, noise, sampler.OUVE(N=4), eps=0.03, snr=0.5,
+                                 corrector_steps=1, denoise=True, n_spkrs=2)
+    out, nfe2 = eng.pc_sample(y, noise, N=4, corrector_steps=1, snr=0.5, t_eps=0.03)
+    assert nfe == nfe2 == 8 and rel_l2(out, ref) < 2e-4
+    eng.close()
+
+
+def test_latentdiffsep_facade_with_reference_ncsnpp_config(tmp_path):
+    """The reference's own score-model config block (default.yaml:16-28, reduced nf) selects the native NCSN++."""
+    from ditsep_amd import LatentDiffSep
+    from oracle import ncsnpp as oncs
+
+    conf = _tiny_config(tmp_path)
+    conf["model"]["score_model"] = {"_target_": "models.diffsep.score_models.LatentScoreModelNCSNpp", "num_sources": 2,
+                                    "backbone_args": {"_target_": "models.diffsep.ncsnpp.NCSNpp", "nf": 32,
+                                                      "ch_mult": [1, 2, 2], "num_res_blocks": 2,
+                                                      "attn_resolutions": [16], "resamp_with_conv": True,
+                                                      "image_size": 64, "centered": True},
+                                    "max_latent_length": 4}
+    ncfg = oncs.NCSNppConfig(nf=32)
+    nsd = oncs.random_ncsnpp_weights(ncfg, 9, out_gain=0.02)
+    vcfg = ovae.OobleckConfig(channels=32)
+    vsd = tiny_vae_weights(vcfg, 31)
+    model = LatentDiffSep(conf, precision="bf16x3")
+    sd = {"score_model." + k: v for k, v in nsd.items()}
+    sd.update({"vae." + k: v for k, v in vsd.items()})
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(35)
+    mix = 0.3 * torch.randn((2, 1, 9000), generator=g)           # T = 5 -> padded to 8 inside the score net
+    ref = pipeline.separate(oncs.NCSNppScore(nsd, ncfg), vsd, vcfg, mix, sampler.OUVE(N=4), 36, n_spkrs=2, eps=0.03,
+                            snr=0.5, corrector_steps=1, target_dim=9000)
+    est, nfe = model.separate(mix, 9000, vae_noise=ref["vae_noise"], noise=ref["noise"])
+    assert nfe == 8 and rel_l2(est, ref["wav"]) < 1e-3
+    model.close()
