@@ -404,3 +404,79 @@ def test_latentdiffsep_facade_with_reference_ncsnpp_config(tmp_path):
     est, nfe = model.separate(mix, 9000, vae_noise=ref["vae_noise"], noise=ref["noise"])
     assert nfe == 8 and rel_l2(est, ref["wav"]) < 1e-3
     model.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json configurations at full model size
+def _full_models():
+    from ditsep_amd import synthetic
+    dcfg = synthetic.DiTConfig()
+    vcfg = synthetic.OobleckConfig()
+    dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=0.002, skip_gain=0.02)
+    vsd = synthetic.vae_weights(vcfg, 2, dec_in_gain=0.08)
+    return dcfg, vcfg, dsd, vsd
+
+
+@pytest.mark.parametrize("prec,tol", [(FP16, 1e-3), (X3, 1e-4)])
+def test_config_c1_wsj0_shape_full_models(prec, tol):
+    """BASELINE config 1: WSJ0-2mix shape, 8 kHz x 4 s (T=16), N=10, batch 1 -- the reference's own
+    CPU-runnable case -- through separate() with the full-size DiT + Oobleck VAE; waveform rel-L2 and
+    SI-SDR delta (PIT) against the CPU oracle.  Tolerances: 1e-3 rel-L2, 0.05 dB (north star)."""
+    from ditsep_amd import synthetic
+    from oracle import metrics
+
+    torch.set_num_threads(16)
+    dcfg, vcfg, dsd, vsd = _full_models()
+    L, N = 32000, 10
+    src = synthetic.synthetic_sources(1, 2, L, 8000, seed=77)
+    mix = src.sum(1, keepdim=True)
+    ref = pipeline.separate(odit.DiTScore(dsd, dcfg), vsd, vcfg, mix, sampler.OUVE(N=N), 78, n_spkrs=2, eps=0.03,
+                            snr=0.5, corrector_steps=1, target_dim=L)
+    eng = make_engine(dcfg, dsd, vcfg, vsd, precision=prec)
+    wav, nfe = eng.separate(mix, vae_noise=ref["vae_noise"], noise=ref["noise"], N=N, corrector_steps=1, snr=0.5,
+                            t_eps=0.03)
+    assert nfe == 20 and ref["y"].shape[-1] == 16
+    assert rel_l2(wav, ref["wav"]) < tol
+    s_gpu, p_gpu = metrics.si_sdr_pit(src, wav.cpu())
+    s_ref, p_ref = metrics.si_sdr_pit(src, ref["wav"])
+    assert torch.equal(p_gpu, p_ref) and float((s_gpu - s_ref).abs().max()) < 0.05
+    eng.close()
+
+
+def test_config_c4_three_speakers_full_dit():
+    """BASELINE config 4: Libri3Mix shape -- 3 sources (io 192 + 64 concat channels), N=30-style PC steps
+    (shortened to N=3 here; the per-step arithmetic is identical), n_spkrs passed explicitly."""
+    from ditsep_amd import synthetic
+
+    torch.set_num_threads(16)
+    dcfg = synthetic.DiTConfig(n_src=3)
+    dsd = synthetic.random_dit_weights(dcfg, 5, out_gain=0.002, skip_gain=0.02)
+    eng = make_engine(dcfg, dsd, precision=FP16)
+    g = torch.Generator().manual_seed(6)
+    y = torch.randn((2, 1, 64, 32), generator=g)
+    noise = sampler.draw_noise(7, 1 + 3 * 2, (2, 3, 64, 32))
+    ref, nfe = sampler.pc_sample(odit.DiTScore(dsd, dcfg), y, noise, sampler.OUVE(N=3), eps=0.03, snr=0.5,
+                                 corrector_steps=1, n_spkrs=3)
+    out, nfe2 = eng.pc_sample(y, noise, N=3, corrector_steps=1, snr=0.5, t_eps=0.03)
+    assert nfe == nfe2 == 6 and out.shape == (2, 3, 64, 32)
+    assert rel_l2(out, ref) < 1e-3
+    eng.close()
+
+
+def test_config_c5_long_form_shape_full_dit():
+    """BASELINE config 5 shape: 30 s @ 16 kHz -> T = 235 latent frames (236 tokens, the 16-key-tile
+    attention variant) through the full-size DiT; one score call against the CPU oracle."""
+    from ditsep_amd import synthetic
+
+    torch.set_num_threads(16)
+    dcfg = synthetic.DiTConfig()
+    dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=0.002, skip_gain=0.02)
+    eng = make_engine(dcfg, dsd, precision=FP16)
+    assert eng.cfg.dit_depth == 24
+    g = torch.Generator().manual_seed(8)
+    T = 235
+    xt = 4.0 * torch.randn((1, 2, 64, T), generator=g)
+    mix = torch.randn((1, 1, 64, T), generator=g)
+    t = torch.tensor([0.4])
+    ref = odit.DiTScore(dsd, dcfg)(xt, t, mix)
+    assert rel_l2(eng.score(xt, t, mix), ref) < 3e-3
+    eng.close()
