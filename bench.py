@@ -174,8 +174,18 @@ def main():
     step(10_000)
     prof = eng.profile_end()
     ach = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12
+    # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs over scripts/pmc_workload.py, gfx950 corrections applied by scripts/pmc_summary.py),
+    # weighted like one bench step: N_STEPS*(CORR+1) score calls + one decode.
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.precision}_{args.score}.json")
+    if os.path.exists(pmc_file) and B == 64:
+        pm = json.load(open(pmc_file))
+        nfe = N_STEPS * (CORR + 1)
+        launches = nfe * pm["igemm_launches_per_score_call"] + pm["igemm_launches_per_decode"]
+        traffic = round((nfe * pm["score_call_hbm_bytes"] + pm["decode_hbm_bytes"]) / launches)
     roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
                 "kernel": "igemm2_kernel (implicit-GEMM MFMA, %s)" % args.precision, "launches_per_step": prof["gemm_launches"],
                 "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
                 "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
