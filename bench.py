@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--score", choices=["dit", "ncsnpp"], default="dit",
                     help="dit: the north-star DiT score network (ditsep.json dims); ncsnpp: the NCSN++ the reference wires in")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="issue decode(i) and sampler(i+1) on separate streams (measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary-precision measurement")
     args = ap.parse_args()
@@ -102,11 +104,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DITSEP_FORCE_DIST"):     # DITSEP_FORCE_DIST: rehearse the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -136,18 +137,36 @@ def main():
     if dist is not None and rank == 0:
         gather_buf = [torch.empty((B, dcfg.n_src, L), device=dev) for _ in range(world)]
 
+    # Two HIP streams: the sampler of batch i+1 (MFMA / L2 bound) is issued while the decode of batch i
+    # (HBM bound) and its gather are still running -- batches are independent, every step still does
+    # all of its work inside the timed region (both streams are drained before the clock stops).
+    s_samp, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    pipelined = args.pipeline
+
     def step(i, engine=eng):
-        x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
-                                  denoise=True, seed=1000 * rank + i)
-        wav = engine.decode(x, L)
-        if dist is not None:
-            dist.gather(wav, gather_buf, dst=0)
+        if not pipelined:
+            x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
+                                      denoise=True, seed=1000 * rank + i)
+            wav = engine.decode(x, L)
+            if dist is not None:
+                dist.gather(wav, gather_buf, dst=0)
+            return wav, nfe
+        with torch.cuda.stream(s_samp):
+            x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
+                                      denoise=True, seed=1000 * rank + i)
+            ready = s_samp.record_event()
+        s_dec.wait_event(ready)
+        with torch.cuda.stream(s_dec):
+            x.record_stream(s_dec)
+            wav = engine.decode(x, L)
+            if dist is not None:
+                dist.gather(wav, gather_buf, dst=0)
         return wav, nfe
 
     def timed(k, w, engine=eng):
         for i in range(w):
             step(i, engine)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()          # device-wide: drains both pipeline streams
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -204,6 +223,7 @@ def main():
                    "score_net": score_desc,
                    "vae": "Oobleck decoder 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
                    "global_batch": world * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
+                   "pipelined_decode": pipelined,
                    "parallelism": f"dp{world}: batch sharded, one RCCL gather of waveforms per step"},
         "roofline": roofline,
     }

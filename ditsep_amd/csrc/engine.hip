@@ -124,8 +124,11 @@ struct dsn_ctx {
   Packed enc_out;
 
   std::map<std::string, Graph> graphs;
-  hipStream_t own = nullptr;  // capture / replay stream (graphs cannot be captured on the NULL stream)
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // capture / replay streams (graphs cannot be captured on the NULL stream): one per entry-point family,
+  // so that the decode of one batch can overlap the sampler of the next when the caller issues them on
+  // different streams (bench.py pipelines them)
+  hipStream_t own[2] = {nullptr, nullptr};
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   bool profiling = false;
   std::vector<ProfRec> prof;
   std::vector<float> tv_host;  // uploaded timestep table signature
@@ -172,21 +175,21 @@ struct dsn_ctx {
   }
   // stream the engine enqueues on: the caller's in eager mode, its own (ordered after the
   // caller's by an event) in graph mode
-  hipStream_t enter(hipStream_t caller) {
+  hipStream_t enter(hipStream_t caller, int which = 0) {
     if (!use_graphs || profiling) return caller;
-    if (!own) {
-      HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    if (!own[which]) {
+      HIPCHK(hipStreamCreateWithFlags(&own[which], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ev_in[which], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_out[which], hipEventDisableTiming));
     }
-    HIPCHK(hipEventRecord(ev_in, caller));
-    HIPCHK(hipStreamWaitEvent(own, ev_in, 0));
-    return own;
+    HIPCHK(hipEventRecord(ev_in[which], caller));
+    HIPCHK(hipStreamWaitEvent(own[which], ev_in[which], 0));
+    return own[which];
   }
-  void leave(hipStream_t caller, hipStream_t used) {
+  void leave(hipStream_t caller, hipStream_t used, int which = 0) {
     if (used == caller) return;
-    HIPCHK(hipEventRecord(ev_out, used));
-    HIPCHK(hipStreamWaitEvent(caller, ev_out, 0));
+    HIPCHK(hipEventRecord(ev_out[which], used));
+    HIPCHK(hipStreamWaitEvent(caller, ev_out[which], 0));
   }
 
   // ---------------------------------------------------------------- memory
@@ -972,9 +975,11 @@ void dsn_destroy(dsn_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& g : ctx->graphs)
     if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
-  if (ctx->own) (void)hipStreamDestroy(ctx->own);
-  if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
-  if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->own[k]) (void)hipStreamDestroy(ctx->own[k]);
+    if (ctx->ev_in[k]) (void)hipEventDestroy(ctx->ev_in[k]);
+    if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
+  }
   for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& kv : ctx->ws) (void)hipFree(kv.second.first);
@@ -1086,7 +1091,7 @@ int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int tar
     if (Lt > Lfull) fail(DSN_EINVAL, "target_len %ld > decoded length %ld", Lt, Lfull);
     const long esz = (long)S * ctx->cfg.latent_dim * T;
     float* eb = ctx->wsbuf<float>("dec_est", esz);
-    hipStream_t st = ctx->enter(caller);
+    hipStream_t st = ctx->enter(caller, 1);
     HIPCHK(hipMemcpyAsync(eb, est, sizeof(float) * esz, hipMemcpyDeviceToDevice, st));
     char key[64];
     snprintf(key, sizeof key, "dec:%d:%d", S, T);
@@ -1095,7 +1100,7 @@ int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int tar
     if (!w) w = ctx->wsbuf<float>("dec_wav", (long)S * Lfull);
     HIPCHK(hipMemcpy2DAsync(wav, sizeof(float) * Lt, w, sizeof(float) * Lfull, sizeof(float) * Lt, S,
                             hipMemcpyDeviceToDevice, st));
-    ctx->leave(caller, st);
+    ctx->leave(caller, st, 1);
   });
 }
 
@@ -1252,6 +1257,13 @@ int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int 
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     auto launch = [&] {
+      d.m_fast = (variant & 0x40) ? 1 : 0;
+      if (variant & 0x20) {
+        d.panel_rows = (variant >> 8) & 0xfff;
+        hipError_t e2 = igemm_panel_launch(d, PL, (variant >> 20) & 0x3ff, nullptr);
+        if (e2 != hipSuccess) fail(DSN_EHIP, "bench panel launch: %s", hipGetErrorString(e2));
+        return;
+      }
       hipError_t e = variant == 1 ? igemm_launch(d, PL, nullptr)
                                   : igemm2_launch_cfg(d, PL, (variant >> 8) & 0xfff, (variant >> 20) & 0x3ff,
                                                       variant & 0xf, (variant & 0x10) ? 64 : 32, nullptr);

@@ -59,6 +59,9 @@ struct GemmDesc {
   const float* rope_sin;
   int rope_S, qkv_D;
   float q_scale;
+  int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
+  int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)
+  int m_fast;      // tile order inside an XCD's share: 1 = row panels fastest (few rows, many columns)
 };
 
 // launchers (igemm.hip)
@@ -66,3 +69,5 @@ hipError_t igemm_launch(const GemmDesc& d, int pl, hipStream_t stream);   // v1:
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream);  // v2: glds ring + split-K, auto tile
 hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, int bk, hipStream_t stream);
 // `pl` = DSN_PL(plane count, fp16 flag)
+// row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
+hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);

@@ -18,6 +18,10 @@
 // 16-byte slots of the 256-byte bank row.
 #include "igemm.h"
 
+#ifndef DSN_DBG_MODE
+#define DSN_DBG_MODE 0  // development ablation builds: 1 = no in-loop staging, 2 = no MFMAs
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -25,22 +29,24 @@ constexpr int TILE_ELEMS = 128 * BK;  // one operand plane tile
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
 
-template <int P, int F16>
-__device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
-                                              int z) {
+// Generic epilogue of one wave: NT column sub-tiles x MT row sub-tiles of 16x16 accumulators starting
+// at (row mw0, column nw0); rows at or beyond m_end are not stored.
+template <int P, int F16, int NT, int MT>
+__device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
+                                             int lane, int z) {
   const int nq = (lane >> 4) * 4;
   if (d.ksplit > 1) {  // raw partial sums to this slice's slab
     float* slab = d.out_f32 + (long)z * d.slab_stride;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+    for (int tm = 0; tm < MT; ++tm) {
       const int m = mw0 + tm * 16 + (lane & 15);
-      if (m >= d.M) continue;
+      if (m >= m_end) continue;
       const int b = m / d.rows_per_b;
       const int j = m - b * d.rows_per_b;
       const long row_rel = (long)j * d.out_row_elems + d.out_off;
       const long row_abs = (long)b * d.out_bstride + row_rel;
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
+      for (int tn = 0; tn < NT; ++tn) {
         const int n = nw0 + tn * 16 + nq;
         if (n >= d.N) continue;
         const long rel = row_rel + n;
@@ -51,9 +57,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
     return;
   }
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
+  for (int tm = 0; tm < MT; ++tm) {
     const int m = mw0 + tm * 16 + (lane & 15);
-    if (m >= d.M) continue;
+    if (m >= m_end) continue;
     const int b = m / d.rows_per_b;
     const int j = m - b * d.rows_per_b;
     const long row_rel = (long)j * d.out_row_elems + d.out_off;
@@ -64,7 +70,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
         // rotary embedding on the first 32 features (pairs (c, c+16) = accumulator tiles 0 and 1 of the
         // same lane), q pre-scaled by 1/sqrt(dh)
         const int section = nw0 / d.qkv_D;
-        if (section < 2) {
+        if (section < 2 && (nw0 & 63) == 0) {   // rotary features live in the first two 16-tiles of a head
           const int pos = m % d.rope_S;
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + nq);
           const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + nq);
@@ -76,7 +82,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
         }
       }
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
+      for (int tn = 0; tn < NT; ++tn) {
         const int n = nw0 + tn * 16 + nq;
         if (n >= d.N) continue;
         const long rel = row_rel + n;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
     } else {
       // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
 #pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
+      for (int tp = 0; tp < NT / 2; ++tp) {
         const int np = nw0 + tp * 32;
         if (np >= d.N) continue;
         const int feat = (np >> 1) + nq;
@@ -151,6 +157,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4]
       }
     }
   }
+}
+
+template <int P, int F16>
+__device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
+                                              int z) {
+  epilogue_gen<P, F16, 4, 4>(d, acc, mw0, d.M, nw0, lane, z);
 }
 
 template <int P, int F16>
@@ -320,6 +332,57 @@ hipError_t igemm_launch(const GemmDesc& din, int pl, hipStream_t stream) {
 // ============================================================================
 namespace {
 
+// Loader state of one staged row (one 16-byte chunk slot of it) for the glds kernels: the row's base
+// pointer per plane (tap 0, channel chunk 0) and a bitmask of the taps for which the row exists
+// (conv zero padding / M,N tails -> zero page).  Everything that varies per k-tile is wave-uniform:
+// a scalar element offset added to the base.
+struct RowLoad {
+  const op16_t* ptr;  // plane 0; plane p adds p * ps
+  long ps;
+  unsigned mask;
+  bool is_a;
+};
+
+__device__ __forceinline__ RowLoad make_row(const GemmDesc& d, bool is_a, int m_or_n, bool in_range, int gchunk, int Ktot) {
+  RowLoad r;
+  r.is_a = is_a;
+  if (is_a) {
+    const int b = m_or_n / d.rows_per_b;
+    const int j = m_or_n - b * d.rows_per_b;
+    const int js = j * d.in_stride - d.in_pad;
+    r.ptr = d.A + (long)b * d.in_bstride + (long)js * d.in_row_elems + gchunk * 8;
+    r.ps = d.a_ps;
+    unsigned mk = 0;
+    if (in_range) {
+      if (d.img_w > 0) {
+        const int y = j / d.img_w, x = j - y * d.img_w;
+        for (int t = 0; t < d.taps; ++t) {
+          const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+          if ((unsigned)(y + dy) < (unsigned)d.img_h && (unsigned)(x + dx) < (unsigned)d.img_w) mk |= 1u << t;
+        }
+      } else {
+        for (int t = 0; t < d.taps; ++t)
+          if ((unsigned)(js + t * d.tap_dil) < (unsigned)d.Lin) mk |= 1u << t;
+      }
+    }
+    r.mask = mk;
+  } else {
+    r.ptr = d.W + (long)m_or_n * Ktot + gchunk * 8;
+    r.ps = d.w_ps;
+    r.mask = in_range ? 0xffffffffu : 0u;
+  }
+  return r;
+}
+
+// wave-uniform element offsets of k-tile (tap, kc): activation rows / weight rows
+__device__ __forceinline__ long a_tile_off(const GemmDesc& d, int tap, int kc, int bk) {
+  const int roff = d.img_w > 0 ? (tap / 3 - 1) * d.img_w + (tap - (tap / 3) * 3 - 1) : tap * d.tap_dil;
+  return (long)roff * d.in_row_elems + kc * bk;
+}
+__device__ __forceinline__ long w_tile_off(const GemmDesc& d, int tap, int kc, int bk) {
+  return (long)tap * d.Cin + kc * bk;
+}
+
 // swizzle of the 16-byte chunk index inside a TBK-wide LDS row (conflict-free ds_read_b128 of
 // MFMA fragments: rows 64 B -> 4 rows per 256-B bank window, rows 128 B -> 2 rows per window)
 template <int TBK>
@@ -355,7 +418,11 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   const int ntiles = d.tiles_m * d.tiles_n;
   const int z = t / ntiles;
   const int tile = t - z * ntiles;
-  const int tile_m = tile / d.tiles_n, tile_n = tile - tile_m * d.tiles_n;
+  // m_fast: consecutive tiles (one XCD's share) walk DOWN the rows of a few column tiles, so the XCD's
+  // L2 keeps its weight columns and streams the (small) activation panels -- for GEMMs with few rows and
+  // many columns (DiT); default walks ACROSS the columns of a few row panels (conv stacks: huge M, small N).
+  const int tile_m = d.m_fast ? tile % d.tiles_m : tile / d.tiles_n;
+  const int tile_n = d.m_fast ? tile / d.tiles_m : tile - tile_m * d.tiles_n;
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
   const int Ktot = d.taps * d.Cin;
@@ -366,61 +433,38 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   const int nkt = kt_end - kt_begin;
 
   // ---- loader role: this wave stages row groups [wave*GPW, wave*GPW + GPW) ----
-  // unified row addressing: r = js + tap*dil must lie in [0, lim);
-  // element offset = base + r*row_elems + tap*tap_elems + kc*TBK
   const int rsub = lane / CPR, cpos = lane % CPR;
-  const op16_t* r_src[GPW];
-  long r_ps[GPW];
-  int r_js[GPW], r_dil[GPW];
-  unsigned r_lim[GPW];
-  long r_rowel[GPW], r_tapel[GPW];
-  bool r_ok[GPW], r_2d[GPW];
-  int r_y[GPW], r_x[GPW];
+  RowLoad rl[GPW];
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave * GPW + gi;
     const bool is_a = g < TBM / RPG;
     const int row = (is_a ? g : g - TBM / RPG) * RPG + rsub;
     const int gchunk = cpos ^ swzk<TBK>(row);  // source chunk held by this lane's LDS slot
-    const int m = m0 + row;
-    const int b = m / d.rows_per_b;
-    const int j = m - b * d.rows_per_b;
-    const int n = n0 + row;
-    r_ok[gi] = is_a ? (m < d.M) : (n < d.N);
-    r_src[gi] = (is_a ? d.A + (long)b * d.in_bstride : d.W + (long)n * Ktot) + gchunk * 8;
-    r_ps[gi] = is_a ? d.a_ps : d.w_ps;
-    r_js[gi] = is_a ? j * d.in_stride - d.in_pad : 0;
-    r_dil[gi] = is_a ? d.tap_dil : 0;
-    r_lim[gi] = is_a ? (unsigned)d.Lin : 1u;
-    r_rowel[gi] = is_a ? d.in_row_elems : 0;
-    r_tapel[gi] = is_a ? 0 : d.Cin;
-    r_y[gi] = (d.img_w > 0 && is_a) ? j / d.img_w : 0;
-    r_x[gi] = (d.img_w > 0 && is_a) ? j - r_y[gi] * d.img_w : 0;
-    r_2d[gi] = d.img_w > 0 && is_a;
+    const int idx = (is_a ? m0 : n0) + row;
+    rl[gi] = make_row(d, is_a, idx, is_a ? idx < d.M : idx < d.N, gchunk, Ktot);
   }
   const op16_t* zsrc = zero_page + cpos * 8;
+  int itap = kt_begin / kc_per_tap, ikc = kt_begin - itap * kc_per_tap;  // (tap, chunk) of the next tile to issue
 
-  auto issue = [&](int kt, int stage) {
-    const int tap = kt / kc_per_tap;
-    const int kc = kt - tap * kc_per_tap;
+  auto issue = [&](int stage) {
     op16_t* sbase = lds + stage * STAGE_ELEMS + wave * GPW * RPG * TBK;
+    const long offa = a_tile_off(d, itap, ikc, TBK), offw = w_tile_off(d, itap, ikc, TBK);
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
-      int r = r_js[gi] + tap * r_dil[gi];
-      bool ok = r_ok[gi] && (unsigned)r < r_lim[gi];
-      if (r_2d[gi]) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        ok = r_ok[gi] && (unsigned)(r_y[gi] + dy) < (unsigned)d.img_h && (unsigned)(r_x[gi] + dx) < (unsigned)d.img_w;
-        r = r_js[gi] + dy * d.img_w + dx;
-      }
-      const op16_t* g0 = r_src[gi] + (long)r * r_rowel[gi] + tap * r_tapel[gi] + kc * TBK;
+      const bool ok = (rl[gi].mask >> itap) & 1u;
+      const op16_t* g0 = rl[gi].ptr + (rl[gi].is_a ? offa : offw);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const op16_t* g = ok ? g0 + p * r_ps[gi] : zsrc;
+        const op16_t* g = ok ? g0 + p * rl[gi].ps : zsrc;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + gi * RPG * TBK),
                                          16, 0, 0);
       }
+    }
+    if (++ikc == kc_per_tap) {
+      ikc = 0;
+      ++itap;
     }
   };
 
@@ -438,7 +482,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nkt) issue(kt_begin + s, s);
+    if (s < nkt) issue(s);
 
   for (int i = 0; i < nkt; ++i) {
     // tile i has landed once at most the loads of the NST-2 younger tiles are outstanding
@@ -450,9 +494,18 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of tile i landed; everyone finished tile i-1
-    if (i + NST - 1 < nkt) issue(kt_begin + i + NST - 1, (i + NST - 1) % NST);
+#if DSN_DBG_MODE != 1
+    if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
+#endif
 
     const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
+#if DSN_DBG_MODE == 2
+    {
+      op16x8 v = *reinterpret_cast<const op16x8*>(base + a_row_off);
+      asm volatile("" ::"v"(v));
+      continue;
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int coff = ((ks * 4 + fchunk) ^ fsw) * 8;
@@ -479,6 +532,143 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     }
   }
   epilogue_tile<P, F16>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+}
+
+// ============================================================================
+// Row-panel variant for GEMMs whose M is a small non-multiple of the tile (the DiT's
+// M = B*(T+1) = 2112 token rows): the rows are cut into equal PANELS of d.panel_rows (<= MT*16) rows --
+// e.g. 8 panels of 264 -- so that panels x column tiles (x split-K) is exactly the CU count and the
+// whole GEMM is ONE balanced round.  A workgroup owns one panel x (NWAVES*32) columns; every wave
+// holds all MT row sub-tiles x 2 column sub-tiles (acc[2][MT]); the last row sub-tile is partly
+// masked.  Staging / ring / swizzle as in igemm2_kernel (BK = 32); row groups are dealt round-robin
+// to the waves, so the per-wave glds count (and its vmcnt) differs by one between waves.
+// ============================================================================
+template <int P, int F16, int NWAVES, int NST, int MT>
+__global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmDesc d,
+                                                                       const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows (MT*16) | W rows (TBN)][32]
+  constexpr int TBN = NWAVES * 32;
+  constexpr int AROWS = MT * 16;
+  constexpr int ROWS = AROWS + TBN;
+  constexpr int PLANE_ELEMS = ROWS * BK;
+  constexpr int STAGE_ELEMS = P * PLANE_ELEMS;
+  constexpr int GROUPS = ROWS / 16;
+  constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;  // max groups per wave
+  constexpr int REM = GROUPS % NWAVES;                 // waves < REM carry GPW groups, the rest GPW-1 (REM==0: all GPW)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int ntiles = d.tiles_m * d.tiles_n;
+  const int z = t / ntiles;
+  const int tile = t - z * ntiles;
+  const int tile_m = d.m_fast ? tile % d.tiles_m : tile / d.tiles_n;
+  const int tile_n = d.m_fast ? tile / d.tiles_m : tile - tile_m * d.tiles_n;
+  const int m0 = tile_m * d.panel_rows, n0 = tile_n * TBN;
+  const int m_end = min(m0 + d.panel_rows, d.M);
+
+  const int Ktot = d.taps * d.Cin;
+  const int kc_per_tap = d.Cin / BK;
+  const int nkt_all = d.taps * kc_per_tap;
+  const int kt_begin = (int)((long)nkt_all * z / d.ksplit);
+  const int kt_end = (int)((long)nkt_all * (z + 1) / d.ksplit);
+  const int nkt = kt_end - kt_begin;
+
+  const int rsub = lane >> 2, cpos = lane & 3;
+  RowLoad rl[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + gi * NWAVES;  // round-robin deal
+    const bool is_a = g < MT;
+    const int row = (is_a ? g : g - MT) * 16 + rsub;
+    const int gchunk = cpos ^ swzk<32>(row);
+    const int idx = (is_a ? m0 : n0) + row;
+    rl[gi] = make_row(d, is_a, idx, g < GROUPS && (is_a ? idx < m_end : idx < d.N), gchunk, Ktot);
+  }
+  const op16_t* zsrc = zero_page + cpos * 8;
+  int itap = kt_begin / kc_per_tap, ikc = kt_begin - itap * kc_per_tap;
+
+  auto issue = [&](int stage) {
+    op16_t* sbase = lds + stage * STAGE_ELEMS;
+    const long offa = a_tile_off(d, itap, ikc, BK), offw = w_tile_off(d, itap, ikc, BK);
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      if (gi < my_groups) {
+        const int g = wave + gi * NWAVES;
+        const bool ok = (rl[gi].mask >> itap) & 1u;
+        const op16_t* g0 = rl[gi].ptr + (rl[gi].is_a ? offa : offw);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const op16_t* gp = ok ? g0 + p * rl[gi].ps : zsrc;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                           (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + g * 16 * BK),
+                                           16, 0, 0);
+        }
+      }
+    }
+    if (++ikc == kc_per_tap) {
+      ikc = 0;
+      ++itap;
+    }
+  };
+
+  f32x4 acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int coff = (fchunk ^ swzk<32>(frow)) * 8;
+  const int a_row_off = frow * BK + coff;
+  const int w_row_off = (AROWS + wave * 32 + frow) * BK + coff;
+
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2)
+    if (s2 < nkt) issue(s2);
+
+  for (int i = 0; i < nkt; ++i) {
+    const int younger = min(NST - 2, nkt - 1 - i);
+    if (NST >= 3 && younger >= 1) {
+      if (REM == 0 || wave < REM)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW * P) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GPW - 1) * P) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
+
+    const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
+    op16x8 fw[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * BK);
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+      op16x8 fa[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        fa[p] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + tm * 16 * BK);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        if (P == 2) {
+          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0], acc[tn][tm]);
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1], acc[tn][tm]);
+        }
+        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0], acc[tn][tm]);
+      }
+    }
+  }
+  epilogue_gen<P, F16, 2, MT>(d, acc, m0, m_end, n0 + wave * 32, lane, z);
 }
 
 const op16_t* zero_page() {
@@ -512,6 +702,7 @@ hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
 hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int nst, int bk, hipStream_t stream) {
   const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   GemmDesc d = din;
+
   if (d.ksplit < 1) d.ksplit = 1;
   if (d.Cin % bk != 0 || d.M <= 0 || d.N <= 0) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
@@ -570,4 +761,41 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
     bk = 64;
   }
   return igemm2_launch_cfg(d, pl, bm, bn, nst, bk, stream);
+}
+
+// Row-panel launcher: d.panel_rows rows per workgroup (<= 272), bn in {128, 256}.
+template <int P, int F16, int NWAVES, int NST>
+static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
+  constexpr int MT = 17;
+  constexpr int TBN = NWAVES * 32;
+  d.tiles_m = cdiv(d.M, d.panel_rows);
+  d.tiles_n = cdiv(d.N, TBN);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, NWAVES, NST, MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int grid = d.tiles_m * d.tiles_n * d.ksplit;
+  const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * BK * sizeof(op16_t);
+  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, NWAVES, NST, MT>), dim3(grid), dim3(NWAVES * 64), smem, stream, d, zp);
+  return hipGetLastError();
+}
+
+hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t stream) {
+  const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
+  GemmDesc d = din;
+  if (d.ksplit < 1) d.ksplit = 1;
+  if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 || d.panel_rows > 17 * 16) return hipErrorInvalidValue;
+  if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
+  if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
+  if (d.img_w > 0) return hipErrorInvalidValue;
+  const op16_t* zp = zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+#define PCFG(P_, W_, NS_)                                                                        \
+  if (planes == P_ && bn == W_ * 32)                                                             \
+    return f16 ? launch_panel_t<P_, 1, W_, NS_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_>(d, zp, stream);
+  PCFG(1, 8, 3) PCFG(1, 4, 3) PCFG(2, 8, 2) PCFG(2, 4, 2)
+#undef PCFG
+  return hipErrorInvalidValue;
 }

@@ -13,7 +13,7 @@ from typing import Mapping, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libditsep_hip.so")
+LIB_PATH = os.environ.get("DSN_LIB", os.path.join(_HERE, "libditsep_hip.so"))
 
 PREC_BF16 = 1
 PREC_BF16X3 = 2
