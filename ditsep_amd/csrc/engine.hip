@@ -595,6 +595,7 @@ struct dsn_ctx {
         d.rope_S = S;
         d.qkv_D = D;
         d.q_scale = 0.125f;
+        d.m_fast = 1;
         run(d, st);
       }
       launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
@@ -624,6 +625,7 @@ struct dsn_ctx {
         d.out_bstride = M * 4L * D;
         d.out_row_elems = 4 * D;
         d.out_limit = d.out_bstride;
+        d.m_fast = 1;
         run(d, st);
       }
       {
@@ -1146,6 +1148,53 @@ int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const f
   if ((rc = dsn_pc_sample(ctx, y, noise, seed + 1, x, B, T, N, corrector_steps, snr, t_eps, denoise, nfe_out, stream)))
     return rc;
   return dsn_decode(ctx, x, wav, B, T, target_len > 0 ? target_len : L, stream);
+}
+
+// Scale-invariant SDR with permutation-invariant assignment (the step right after the path in
+// evaluate_latent.py:118-136, where the reference calls fast_bss_eval.si_bss_eval_sources with
+// compute_permutation=True).  Device: all n x n correlation / energy sums; host: SI-SDR matrix
+// (no mean removal, eps 1e-10) and the best of the n! <= 24 permutations.
+int dsn_si_sdr_pit(dsn_ctx* ctx, const float* ref, const float* est, int B, int n, int L, float* si_sdr_out,
+                   int* perm_out, void* stream) {
+  return guarded(ctx, [&] {
+    if (!ref || !est || B <= 0 || n <= 0 || n > 4 || L <= 0) fail(DSN_EINVAL, "dsn_si_sdr_pit: bad arguments (n <= 4)");
+    hipStream_t st = (hipStream_t)stream;
+    double* dd = ctx->wsbuf<double>("sisdr", (long)B * n * n * 3);
+    launch_sisdr_dots(ref, est, B, n, L, dd, st);
+    std::vector<double> h((size_t)B * n * n * 3);
+    HIPCHK(hipMemcpyAsync(h.data(), dd, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> p(n);
+    for (int b = 0; b < B; ++b) {
+      // sdr[i][j]: est_j scored against ref_i
+      double sdr[4][4];
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const double* v = &h[(((size_t)b * n + i) * n + j) * 3];
+          const double eps = 1e-10;
+          const double alpha = v[0] / (v[1] + eps);
+          const double tgt = alpha * alpha * v[1];
+          const double noise = v[2] - 2.0 * alpha * v[0] + tgt;
+          sdr[i][j] = 10.0 * log10((tgt + eps) / (noise + eps));
+        }
+      for (int i = 0; i < n; ++i) p[i] = i;
+      double best = -1e300;
+      std::vector<int> bestp = p;
+      do {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += sdr[i][p[i]];
+        s /= n;
+        if (s > best) {
+          best = s;
+          bestp = p;
+        }
+      } while (std::next_permutation(p.begin(), p.end()));
+      for (int i = 0; i < n; ++i) {
+        if (si_sdr_out) si_sdr_out[(size_t)b * n + i] = (float)sdr[i][bestp[i]];
+        if (perm_out) perm_out[(size_t)b * n + i] = bestp[i];
+      }
+    }
+  });
 }
 
 // Development hook: copy `count` floats of the named workspace buffer to host memory.

@@ -89,3 +89,7 @@ void launch_ncsn_fourier(const float* t, const float* w, int B, int nf, op16_t* 
                          hipStream_t s);
 void launch_ncsn_output(const float* pyr, int Cp, const float* t, const float* w, const float* bias, int cin, int n,
                         int B, int H, int T, int Wp, float* score, hipStream_t s);
+
+// ---- metrics -----------------------------------------------------------------------------------------
+// out[(b*n + i)*n + j][3] = (<ref_i, est_j>, |ref_i|^2, |est_j|^2) in fp64
+void launch_sisdr_dots(const float* ref, const float* est, int B, int n, int L, double* out, hipStream_t s);

@@ -661,3 +661,48 @@ void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t st
 void launch_snake_params(const float* alpha, const float* beta, float* a, float* ib, int C, hipStream_t st) {
   hipLaunchKernelGGL(snake_params_kernel, dim3(grid_for(C)), dim3(TPB), 0, st, alpha, beta, a, ib, C);
 }
+
+// ------------------------------------------------------------------ SI-SDR dot products
+// For every (item, ref source i, est source j): <ref_i, est_j>, and the energies |ref_i|^2, |est_j|^2.
+// One workgroup per (item, i, j); wave shuffles + LDS tree; fp32 products accumulated in fp64.
+namespace {
+__global__ __launch_bounds__(256) void sisdr_dots_kernel(const float* __restrict__ ref, const float* __restrict__ est,
+                                                         int n, int L, double* __restrict__ out) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.x / (n * n);
+  const int ij = blockIdx.x - b * n * n;
+  const int i = ij / n, j = ij - i * n;
+  const float* r = ref + ((long)b * n + i) * L;
+  const float* e = est + ((long)b * n + j) * L;
+  double sre = 0.0, srr = 0.0, see = 0.0;
+  for (int k = threadIdx.x; k < L; k += blockDim.x) {
+    const double rv = r[k], ev = e[k];
+    sre += rv * ev;
+    srr += rv * rv;
+    see += ev * ev;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sre += __shfl_xor(sre, o, 64);
+    srr += __shfl_xor(srr, o, 64);
+    see += __shfl_xor(see, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = sre;
+    red[1][wave] = srr;
+    red[2][wave] = see;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = out + (long)blockIdx.x * 3;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    o[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  }
+}
+}  // namespace
+
+void launch_sisdr_dots(const float* ref, const float* est, int B, int n, int L, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sisdr_dots_kernel, dim3(B * n * n), dim3(256), 0, st, ref, est, n, L, out);
+}

@@ -27,7 +27,7 @@ EXPORTS = [
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
-    "dsn_bench_igemm", "dsn_debug_read",
+    "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
 ]
 
 
@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
     lib.dsn_profile_begin.argtypes = [vp]
     lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.dsn_si_sdr_pit.argtypes = [vp, vp, vp, ci, ci, ci, fp, C.POINTER(ci), vp]
     lib.dsn_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
     lib.dsn_bench_igemm.argtypes = [vp] + [ci] * 10 + [C.POINTER(C.c_double)]
     for name in EXPORTS:
@@ -258,6 +259,17 @@ class Engine:
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.dsn_profile_end(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)), "dsn_profile_end")
         return {"gemm_ms": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value}
+
+    def si_sdr_pit(self, ref, est):
+        """ref, est [B,n,L] -> (si_sdr [B,n] dB, perm [B,n]): est[:, perm[b,i]] matches ref[:, i]."""
+        ref, est = _dev32(ref, self.device), _dev32(est, self.device)
+        B, n, L = ref.shape
+        sdr = (C.c_float * (B * n))()
+        perm = (C.c_int * (B * n))()
+        self._check(self.lib.dsn_si_sdr_pit(self.ctx, _ptr(ref), _ptr(est), B, n, L, sdr, perm, self._stream()),
+                    "dsn_si_sdr_pit")
+        return (torch.tensor(list(sdr), dtype=torch.float32).reshape(B, n),
+                torch.tensor(list(perm), dtype=torch.long).reshape(B, n))
 
     def debug_read(self, name: str, shape):
         out = torch.empty(shape, dtype=torch.float32)

@@ -117,6 +117,12 @@ int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const f
                  float* wav, int B, int L, int target_len, int N, int corrector_steps, float snr, float t_eps,
                  int denoise, int* nfe_out, void* stream);
 
+/* SI-SDR with permutation-invariant assignment: ref, est [B,n,L] (device) -> si_sdr [B,n] and perm [B,n]
+ * (host; est source perm[b][i] is matched to ref source i).  Replaces the fast_bss_eval call of
+ * src/evaluate_latent.py:118-136 (compute_permutation=True, zero_mean=False); n <= 4. */
+int dsn_si_sdr_pit(dsn_ctx* ctx, const float* ref, const float* est, int B, int n, int L, float* si_sdr_out,
+                   int* perm_out, void* stream);
+
 /* introspection for benchmarks / tests */
 int dsn_enable_graphs(dsn_ctx* ctx, int enable);          /* hipGraph replay of sample/decode */
 int64_t dsn_workspace_bytes(const dsn_ctx* ctx);
