@@ -578,6 +578,8 @@ struct dsn_ctx {
     // Residual-stream GEMMs (out-proj, FF-out) have N = D only: at M ~ 2k rows that is too few
     // 128x128 tiles to fill 256 CUs, so they run split-K into fp32 slabs and the slab reduction
     // (+ bias + residual) is fused into the LayerNorm that follows.
+    static const bool no_two_part = getenv("DSN_NO_TWO_PART") != nullptr;
+    const bool two_part = !no_two_part && P == 2 && (Mt % 256 == 0) && Mt >= 2048 && (D % 64 == 0);  // measured: +3 % in split modes, -2 % in single-plane modes
     float* slabs = nullptr;
     int pend_n = 0;
     const float* pend_bias = nullptr;
@@ -617,7 +619,35 @@ struct dsn_ctx {
       }
       launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
                            st);
-      {
+      if (two_part) {
+        // FF-in in two launches so that the big one is exactly one balanced round: the B*T content rows
+        // (a multiple of 256) as 256x256 tiles = 8 x 32 workgroups, then the B time-token rows as 128-row
+        // tiles.  Both address the interleaved [B][T+1] row layout through the descriptor.
+        GemmDesc d = base_desc(Ap, M * D, L.ff1, B, T, S);
+        d.in_pad = -1;                      // content rows start at token 1 of every item
+        d.in_bstride = (long)S * D;
+        d.swiglu = 1;
+        d.out_planes = FF;
+        d.out_ps = M * 4 * D;
+        d.out_bstride = (long)S * 4 * D;
+        d.out_row_elems = 4 * D;
+        d.out_off = 4 * D;
+        d.out_limit = d.out_bstride;
+        d.cfg_bm = d.cfg_bn = 256;
+        d.cfg_nst = 2;
+        d.cfg_bk = (P == 1) ? 64 : 32;
+        run(d, st);
+        GemmDesc e2 = base_desc(Ap, M * D, L.ff1, B, 1, S);
+        e2.in_bstride = (long)S * D;
+        e2.swiglu = 1;
+        e2.out_planes = FF;
+        e2.out_ps = M * 4 * D;
+        e2.out_bstride = (long)S * 4 * D;
+        e2.out_row_elems = 4 * D;
+        e2.out_limit = e2.out_bstride;
+        e2.m_fast = 1;
+        run(e2, st);
+      } else {
         GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
         d.swiglu = 1;
         d.out_planes = FF;

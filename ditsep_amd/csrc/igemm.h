@@ -60,6 +60,7 @@ struct GemmDesc {
   int rope_S, qkv_D;
   float q_scale;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
+  int cfg_bm, cfg_bn, cfg_nst, cfg_bk;  // explicit tile configuration for igemm2_launch (0 = heuristic)
   int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)
   int m_fast;      // tile order inside an XCD's share: 1 = row panels fastest (few rows, many columns)
 };

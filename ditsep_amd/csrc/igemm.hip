@@ -547,10 +547,12 @@ template <int P, int F16, int NWAVES, int NST, int MT>
 __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmDesc d,
                                                                        const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows (MT*16) | W rows (TBN)][32]
-  constexpr int TBN = NWAVES * 32;
+  constexpr int WN_ = NWAVES / 2;          // waves: 2 (rows) x WN_ (64-column strips)
+  constexpr int TBN = WN_ * 64;
+  constexpr int MTW = (MT + 1) / 2;        // row sub-tiles of wave row 0 (wave row 1 owns MT - MTW)
   constexpr int AROWS = MT * 16;
   constexpr int ROWS = AROWS + TBN;
-  constexpr int PLANE_ELEMS = ROWS * BK;
+  constexpr int PLANE_ELEMS = (ROWS + 16) * BK;  // +16 rows: wave row 1 may read one sub-tile past the panel
   constexpr int STAGE_ELEMS = P * PLANE_ELEMS;
   constexpr int GROUPS = ROWS / 16;
   constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;  // max groups per wave
@@ -559,6 +561,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
+  const int my_mt = wave_m == 0 ? MTW : MT - MTW;
   const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -617,16 +621,16 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
     }
   };
 
-  f32x4 acc[2][MT];
+  f32x4 acc[4][MTW];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fchunk = lane >> 4;
   const int coff = (fchunk ^ swzk<32>(frow)) * 8;
-  const int a_row_off = frow * BK + coff;
-  const int w_row_off = (AROWS + wave * 32 + frow) * BK + coff;
+  const int a_row_off = (wave_m * MTW * 16 + frow) * BK + coff;
+  const int w_row_off = (AROWS + wave_n * 64 + frow) * BK + coff;
 
 #pragma unroll
   for (int s2 = 0; s2 < NST - 1; ++s2)
@@ -646,29 +650,32 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
     if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
 
     const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
-    op16x8 fw[P][2];
+    op16x8 fw[P][4];
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+      for (int k = 0; k < 4; ++k)
         fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * BK);
 #pragma unroll
-    for (int tm = 0; tm < MT; ++tm) {
-      op16x8 fa[P];
+    for (int tm = 0; tm < MTW; ++tm) {
+      if (tm < my_mt) {
+        op16x8 fa[P];
 #pragma unroll
-      for (int p = 0; p < P; ++p)
-        fa[p] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + tm * 16 * BK);
+        for (int p = 0; p < P; ++p)
+          fa[p] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + tm * 16 * BK);
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        if (P == 2) {
-          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0], acc[tn][tm]);
-          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1], acc[tn][tm]);
+        for (int tn = 0; tn < 4; ++tn) {
+          if (P == 2) {
+            acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0], acc[tn][tm]);
+            acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1], acc[tn][tm]);
+          }
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0], acc[tn][tm]);
         }
-        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0], acc[tn][tm]);
       }
     }
   }
-  epilogue_gen<P, F16, 2, MT>(d, acc, m0, m_end, n0 + wave * 32, lane, z);
+  // wave row 1's unused last sub-tile starts at row AROWS >= panel_rows: masked by m_end
+  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + wave_m * MTW * 16, m_end, n0 + wave_n * 64, lane, z);
 }
 
 const op16_t* zero_page() {
@@ -729,6 +736,7 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
   // Tile choice from the measured sweeps (scripts/gemm_bench.py; profiles/r01_gemm_sweep_*.log).
   // The kernel is L2->LDS bound and, at the DiT's M ~ 2k rows, wave-quantisation bound: take the
   // biggest tile whose grid still fills 256 CUs.
+  if (d.cfg_bm > 0) return igemm2_launch_cfg(d, pl, d.cfg_bm, d.cfg_bn, d.cfg_nst, d.cfg_bk, stream);
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
   if (planes == 2) {
@@ -777,7 +785,7 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
     attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * BK * sizeof(op16_t);
+  const size_t smem = (size_t)NST * P * (MT * 16 + TBN + 16) * BK * sizeof(op16_t);
   hipLaunchKernelGGL((igemm_panel_kernel<P, F16, NWAVES, NST, MT>), dim3(grid), dim3(NWAVES * 64), smem, stream, d, zp);
   return hipGetLastError();
 }
