@@ -52,7 +52,9 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   const int r16 = lane & 15, g = lane >> 4;
   const int tq = r16 >> 2, tp = r16 & 3;  // role inside a 16-lane transposed-read group
 
-  for (int qt = 0; qt < nkt; ++qt) {
+  // one query tile per workgroup (blockIdx.y): short sequences are latency bound, so spread the query
+  // tiles over more waves (V is staged redundantly, it is small)
+  for (int qt = blockIdx.y; qt < nkt; qt += gridDim.y) {
     // ---- scores^T = K Q^T -------------------------------------------------
     const int qrow = min(qt * 16 + r16, S - 1);
     constexpr int KSD = DH / 32;
@@ -181,8 +183,8 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
   const int nkt = (S + 15) / 16;
   const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);
   if (nkt <= 4) {
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S,
-                       H);
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out, out_ps,
+                       S, H);
   } else {
     static bool attr = false;
     if (!attr) {
@@ -190,8 +192,8 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H), dim3(64), sm, st, qkv, ps, out, out_ps, S,
-                       H);
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out,
+                       out_ps, S, H);
   }
 }
 

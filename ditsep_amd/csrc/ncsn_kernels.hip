@@ -220,7 +220,6 @@ void launch_ncsn_pack(const float* xt, const float* mix, int B, int n, int H, in
 }
 void launch_gn_stats(const float* x, long bstride, int rstride, int C, int G, int B, int HW, float* stats,
                      hipStream_t st) {
-  (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * B * G, st);
   if (C / 4 > TPB || G > 64 || C % (4 * G) != 0) return;  // unsupported shape: caller validates (engine: C <= 1024)
   const int rows_per_block = 64;
   hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + rows_per_block - 1) / rows_per_block, B), dim3(TPB), 0, st, x, bstride,
