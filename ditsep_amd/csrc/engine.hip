@@ -502,7 +502,7 @@ struct dsn_ctx {
     k = std::min(k, std::min(8, nkt / 8));
     return std::max(k, 1);
   }
-  void run(const GemmDesc& d, hipStream_t st) {
+  void run(const GemmDesc& d, hipStream_t st, int panel_bn = 0) {
     ProfRec pr;
     if (profiling) {
       HIPCHK(hipEventCreate(&pr.a));
@@ -511,7 +511,8 @@ struct dsn_ctx {
       HIPCHK(hipEventRecord(pr.a, st));
     }
     static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
-    hipError_t e = (use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st);
+    hipError_t e = panel_bn > 0 ? igemm_panel_launch(d, PL, panel_bn, st)
+                                : ((use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st));
     if (profiling) {
       HIPCHK(hipEventRecord(pr.b, st));
       prof.push_back(pr);
@@ -578,8 +579,10 @@ struct dsn_ctx {
     // Residual-stream GEMMs (out-proj, FF-out) have N = D only: at M ~ 2k rows that is too few
     // 128x128 tiles to fill 256 CUs, so they run split-K into fp32 slabs and the slab reduction
     // (+ bias + residual) is fused into the LayerNorm that follows.
-    static const bool no_two_part = getenv("DSN_NO_TWO_PART") != nullptr;
-    const bool two_part = !no_two_part && P == 2 && (Mt % 256 == 0) && Mt >= 2048 && (D % 64 == 0);  // measured: +3 % in split modes, -2 % in single-plane modes
+    static const bool no_panel = getenv("DSN_NO_PANEL") != nullptr;
+    const bool use_panel = !no_panel && (D % 64 == 0);
+    static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
+    const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : 0;
     float* slabs = nullptr;
     int pend_n = 0;
     const float* pend_bias = nullptr;
@@ -598,7 +601,11 @@ struct dsn_ctx {
         d.qkv_D = D;
         d.q_scale = 0.125f;
         d.m_fast = 1;
-        run(d, st);
+        if (qkv_panel) {
+          const int np = cdiv(M, 272);
+          d.panel_rows = (cdiv(M, np) + 7) / 8 * 8;
+        }
+        run(d, st, qkv_panel);
       }
       launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
       {
@@ -619,35 +626,9 @@ struct dsn_ctx {
       }
       launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
                            st);
-      if (two_part) {
-        // FF-in in two launches so that the big one is exactly one balanced round: the B*T content rows
-        // (a multiple of 256) as 256x256 tiles = 8 x 32 workgroups, then the B time-token rows as 128-row
-        // tiles.  Both address the interleaved [B][T+1] row layout through the descriptor.
-        GemmDesc d = base_desc(Ap, M * D, L.ff1, B, T, S);
-        d.in_pad = -1;                      // content rows start at token 1 of every item
-        d.in_bstride = (long)S * D;
-        d.swiglu = 1;
-        d.out_planes = FF;
-        d.out_ps = M * 4 * D;
-        d.out_bstride = (long)S * 4 * D;
-        d.out_row_elems = 4 * D;
-        d.out_off = 4 * D;
-        d.out_limit = d.out_bstride;
-        d.cfg_bm = d.cfg_bn = 256;
-        d.cfg_nst = 2;
-        d.cfg_bk = (P == 1) ? 64 : 32;
-        run(d, st);
-        GemmDesc e2 = base_desc(Ap, M * D, L.ff1, B, 1, S);
-        e2.in_bstride = (long)S * D;
-        e2.swiglu = 1;
-        e2.out_planes = FF;
-        e2.out_ps = M * 4 * D;
-        e2.out_bstride = (long)S * 4 * D;
-        e2.out_row_elems = 4 * D;
-        e2.out_limit = e2.out_bstride;
-        e2.m_fast = 1;
-        run(e2, st);
-      } else {
+      {
+        // FF-in through the row-panel kernel: ceil(M/272) equal row panels x 256-column tiles -- for the
+        // benchmark shape (M = 2112 -> 8 panels of 264 rows, N = 8192) exactly 256 workgroups, one round.
         GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
         d.swiglu = 1;
         d.out_planes = FF;
@@ -656,7 +637,11 @@ struct dsn_ctx {
         d.out_row_elems = 4 * D;
         d.out_limit = d.out_bstride;
         d.m_fast = 1;
-        run(d, st);
+        if (use_panel) {
+          const int np = cdiv(M, 272);
+          d.panel_rows = (cdiv(M, np) + 7) / 8 * 8;
+        }
+        run(d, st, use_panel ? 256 : 0);
       }
       {
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
@@ -1278,7 +1263,7 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
 }
 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N, int taps,
-                   int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream) {
+                   int in_stride, int tap_dil, int in_pad, int rows_per_b, int panel_rows, int panel_bn, void* stream) {
   return guarded(ctx, [&] {
     hipStream_t st = (hipStream_t)stream;
     const int P = ctx->P, PL = ctx->PL;
@@ -1299,7 +1284,13 @@ int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int
     d.tap_dil = tap_dil;
     d.in_pad = in_pad;
     d.out_f32 = out;
-    ctx->run(d, st);
+    if (panel_rows > 0) {
+      d.panel_rows = panel_rows;
+      hipError_t e = igemm_panel_launch(d, PL, panel_bn, st);
+      if (e != hipSuccess) fail(DSN_EHIP, "panel launch: %s", hipGetErrorString(e));
+    } else {
+      ctx->run(d, st);
+    }
     HIPCHK(hipGetLastError());
   });
 }

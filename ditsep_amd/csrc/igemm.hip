@@ -543,26 +543,32 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 // masked.  Staging / ring / swizzle as in igemm2_kernel (BK = 32); row groups are dealt round-robin
 // to the waves, so the per-wave glds count (and its vmcnt) differs by one between waves.
 // ============================================================================
-template <int P, int F16, int NWAVES, int NST, int MT>
-__global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmDesc d,
-                                                                       const op16_t* __restrict__ zero_page) {
-  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows (MT*16) | W rows (TBN)][32]
-  constexpr int WN_ = NWAVES / 2;          // waves: 2 (rows) x WN_ (64-column strips)
+template <int P, int F16, int WN_, int NST, int TBK>
+__global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const GemmDesc d,
+                                                                         const op16_t* __restrict__ zero_page) {
+  // 4 wave rows x WN_ wave columns; wave row 0 owns 5 row sub-tiles (80 rows), rows 1..3 own 4 (64 rows):
+  // 17 sub-tiles = 272 >= panel_rows.  Every wave owns 4 column sub-tiles (64 columns).
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows (272) | W rows (TBN) | pad][TBK]
+  constexpr int NWAVES = 4 * WN_;
+  constexpr int MT = 17, MTW = 5;
   constexpr int TBN = WN_ * 64;
-  constexpr int MTW = (MT + 1) / 2;        // row sub-tiles of wave row 0 (wave row 1 owns MT - MTW)
   constexpr int AROWS = MT * 16;
   constexpr int ROWS = AROWS + TBN;
-  constexpr int PLANE_ELEMS = (ROWS + 16) * BK;  // +16 rows: wave row 1 may read one sub-tile past the panel
+  constexpr int PLANE_ELEMS = ROWS * TBK;
   constexpr int STAGE_ELEMS = P * PLANE_ELEMS;
-  constexpr int GROUPS = ROWS / 16;
+  constexpr int CPR = TBK / 8;
+  constexpr int RPG = 64 / CPR;
+  constexpr int GROUPS = ROWS / RPG;
   constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;  // max groups per wave
   constexpr int REM = GROUPS % NWAVES;                 // waves < REM carry GPW groups, the rest GPW-1 (REM==0: all GPW)
+  constexpr int KS = TBK / 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
-  const int my_mt = wave_m == 0 ? MTW : MT - MTW;
+  const int my_mt = wave_m == 0 ? 5 : 4;
+  const int my_row0 = wave_m == 0 ? 0 : 16 + wave_m * 64;
   const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -577,20 +583,20 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
   const int m_end = min(m0 + d.panel_rows, d.M);
 
   const int Ktot = d.taps * d.Cin;
-  const int kc_per_tap = d.Cin / BK;
+  const int kc_per_tap = d.Cin / TBK;
   const int nkt_all = d.taps * kc_per_tap;
   const int kt_begin = (int)((long)nkt_all * z / d.ksplit);
   const int kt_end = (int)((long)nkt_all * (z + 1) / d.ksplit);
   const int nkt = kt_end - kt_begin;
 
-  const int rsub = lane >> 2, cpos = lane & 3;
+  const int rsub = lane / CPR, cpos = lane % CPR;
   RowLoad rl[GPW];
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave + gi * NWAVES;  // round-robin deal
-    const bool is_a = g < MT;
-    const int row = (is_a ? g : g - MT) * 16 + rsub;
-    const int gchunk = cpos ^ swzk<32>(row);
+    const bool is_a = g < AROWS / RPG;
+    const int row = (is_a ? g : g - AROWS / RPG) * RPG + rsub;
+    const int gchunk = cpos ^ swzk<TBK>(row);
     const int idx = (is_a ? m0 : n0) + row;
     rl[gi] = make_row(d, is_a, idx, g < GROUPS && (is_a ? idx < m_end : idx < d.N), gchunk, Ktot);
   }
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
 
   auto issue = [&](int stage) {
     op16_t* sbase = lds + stage * STAGE_ELEMS;
-    const long offa = a_tile_off(d, itap, ikc, BK), offw = w_tile_off(d, itap, ikc, BK);
+    const long offa = a_tile_off(d, itap, ikc, TBK), offw = w_tile_off(d, itap, ikc, TBK);
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       if (gi < my_groups) {
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
         for (int p = 0; p < P; ++p) {
           const op16_t* gp = ok ? g0 + p * rl[gi].ps : zsrc;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                           (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + g * 16 * BK),
+                                           (__attribute__((address_space(3))) void*)(sbase + p * PLANE_ELEMS + g * RPG * TBK),
                                            16, 0, 0);
         }
       }
@@ -628,9 +634,9 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
     for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fchunk = lane >> 4;
-  const int coff = (fchunk ^ swzk<32>(frow)) * 8;
-  const int a_row_off = (wave_m * MTW * 16 + frow) * BK + coff;
-  const int w_row_off = (AROWS + wave_n * 64 + frow) * BK + coff;
+  const int fsw = swzk<TBK>(frow);
+  const int a_row_off = (my_row0 + frow) * TBK;
+  const int w_row_off = (AROWS + wave_n * 64 + frow) * TBK;
 
 #pragma unroll
   for (int s2 = 0; s2 < NST - 1; ++s2)
@@ -650,32 +656,36 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void igemm_panel_kernel(const GemmD
     if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
 
     const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
-    op16x8 fw[P][4];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = ((ks * 4 + fchunk) ^ fsw) * 8;
+      op16x8 fw[P][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * BK);
+      for (int p = 0; p < P; ++p)
 #pragma unroll
-    for (int tm = 0; tm < MTW; ++tm) {
-      if (tm < my_mt) {
-        op16x8 fa[P];
+        for (int k = 0; k < 4; ++k)
+          fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * TBK + coff);
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-          fa[p] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + tm * 16 * BK);
+      for (int tm = 0; tm < MTW; ++tm) {
+        if (tm < my_mt) {
+          op16x8 fa[P];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          if (P == 2) {
-            acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0], acc[tn][tm]);
-            acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1], acc[tn][tm]);
+          for (int p = 0; p < P; ++p)
+            fa[p] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + tm * 16 * TBK + coff);
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            if (P == 2) {
+              acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0], acc[tn][tm]);
+              acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1], acc[tn][tm]);
+            }
+            acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0], acc[tn][tm]);
           }
-          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0], acc[tn][tm]);
         }
       }
     }
   }
-  // wave row 1's unused last sub-tile starts at row AROWS >= panel_rows: masked by m_end
-  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + wave_m * MTW * 16, m_end, n0 + wave_n * 64, lane, z);
+  // rows m0 + my_row0 + tm*16 ...; wave rows 1..3 never touch their (unused) 5th sub-tile: mask it by row
+  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
 }
 
 const op16_t* zero_page() {
@@ -772,21 +782,20 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
 }
 
 // Row-panel launcher: d.panel_rows rows per workgroup (<= 272), bn in {128, 256}.
-template <int P, int F16, int NWAVES, int NST>
+template <int P, int F16, int WN_, int NST, int TBK>
 static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
-  constexpr int MT = 17;
-  constexpr int TBN = NWAVES * 32;
+  constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, NWAVES, NST, MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * P * (MT * 16 + TBN + 16) * BK * sizeof(op16_t);
-  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, NWAVES, NST, MT>), dim3(grid), dim3(NWAVES * 64), smem, stream, d, zp);
+  const size_t smem = (size_t)NST * P * (17 * 16 + TBN) * TBK * sizeof(op16_t);
+  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d, zp);
   return hipGetLastError();
 }
 
@@ -794,16 +803,16 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
   const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
-  if (d.Cin % BK != 0 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 || d.panel_rows > 17 * 16) return hipErrorInvalidValue;
+  if (d.Cin % 64 != 0 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 || d.panel_rows > 17 * 16) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   if (d.img_w > 0) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define PCFG(P_, W_, NS_)                                                                        \
-  if (planes == P_ && bn == W_ * 32)                                                             \
-    return f16 ? launch_panel_t<P_, 1, W_, NS_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_>(d, zp, stream);
-  PCFG(1, 8, 3) PCFG(1, 4, 3) PCFG(2, 8, 2) PCFG(2, 4, 2)
+#define PCFG(P_, W_, NS_, BK_)                                                                   \
+  if (planes == P_ && bn == W_ * 64)                                                             \
+    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_>(d, zp, stream);
+  PCFG(1, 4, 2, 64) PCFG(1, 2, 2, 64) PCFG(2, 4, 2, 32) PCFG(2, 2, 2, 32)
 #undef PCFG
   return hipErrorInvalidValue;
 }

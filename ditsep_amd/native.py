@@ -83,7 +83,7 @@ def load_library() -> C.CDLL:
     lib.dsn_workspace_bytes.argtypes = [vp]
     lib.dsn_profile_begin.argtypes = [vp]
     lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.dsn_si_sdr_pit.argtypes = [vp, vp, vp, ci, ci, ci, fp, C.POINTER(ci), vp]
     lib.dsn_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
     lib.dsn_bench_igemm.argtypes = [vp] + [ci] * 10 + [C.POINTER(C.c_double)]
@@ -283,7 +283,8 @@ class Engine:
                                              iters, C.byref(ms)), "dsn_bench_igemm")
         return ms.value
 
-    def test_igemm(self, a, w, *, taps=1, in_stride=1, tap_dil=1, in_pad=0, rows_per_b=None):
+    def test_igemm(self, a, w, *, taps=1, in_stride=1, tap_dil=1, in_pad=0, rows_per_b=None, panel_rows=0,
+                   panel_bn=256):
         """a [B,Lin,Cin] channels-last, w [N, taps*Cin] -> [B, rows_per_b, N] (kernel test hook)."""
         a, w = _dev32(a, self.device), _dev32(w, self.device)
         B, Lin, Cin = a.shape
@@ -291,5 +292,5 @@ class Engine:
         rpb = rows_per_b or Lin
         out = torch.empty((B, rpb, N), device=self.device, dtype=torch.float32)
         self._check(self.lib.dsn_test_igemm(self.ctx, _ptr(a), _ptr(w), _ptr(out), B, Lin, Cin, N, taps, in_stride,
-                                            tap_dil, in_pad, rpb, self._stream()), "dsn_test_igemm")
+                                            tap_dil, in_pad, rpb, panel_rows, panel_bn, self._stream()), "dsn_test_igemm")
         return out

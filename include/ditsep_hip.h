@@ -136,7 +136,8 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
 /* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
  * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N,
-                   int taps, int in_stride, int tap_dil, int in_pad, int rows_per_b, void* stream);
+                   int taps, int in_stride, int tap_dil, int in_pad, int rows_per_b, int panel_rows, int panel_bn,
+                   void* stream);   /* panel_rows > 0: row-panel kernel with panel_bn (128|256) columns */
 
 /* Development hook: copy `count` floats of a named workspace buffer to host memory. */
 int dsn_debug_read(dsn_ctx* ctx, const char* name, float* host, int64_t count);

@@ -72,6 +72,17 @@ def test_igemm_strided_conv(bare, stride):
     assert rel_l2(out, ref) < TOL[X3]
 
 
+@pytest.mark.parametrize("prec", [X3, FP16])
+@pytest.mark.parametrize("M,rows,bn", [(2112, 264, 256), (2112, 264, 128), (66, 72, 256), (500, 256, 128), (1000, 200, 256)])
+def test_igemm_row_panel_kernel(bare, prec, M, rows, bn):
+    """Row-panel GEMM variant (equal row panels <= 272 rows; last sub-tile partly masked)."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((1, M, 128), generator=g)
+    w = torch.randn((320, 128), generator=g) / math.sqrt(128)
+    out = bare[prec].test_igemm(a, w, panel_rows=rows, panel_bn=bn)
+    assert rel_l2(out, a.double() @ w.double().t()) < TOL[prec]
+
+
 def test_igemm_empty_and_ragged_edges(bare):
     # M not a multiple of the 128-row tile, N not a multiple of 128, K = one 32-chunk
     g = torch.Generator().manual_seed(4)
