@@ -146,14 +146,14 @@ def main():
     def step(i, engine=eng):
         if not pipelined:
             x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
-                                      denoise=True, seed=1000 * rank + i)
+                                      denoise=True, seed=(1000 * rank + i) & 0x7FFFFFFF)
             wav = engine.decode(x, L)
             if dist is not None:
                 dist.gather(wav, gather_buf, dst=0)
             return wav, nfe
         with torch.cuda.stream(s_samp):
             x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
-                                      denoise=True, seed=1000 * rank + i)
+                                      denoise=True, seed=(1000 * rank + i) & 0x7FFFFFFF)
             ready = s_samp.record_event()
         s_dec.wait_event(ready)
         with torch.cuda.stream(s_dec):
@@ -164,6 +164,10 @@ def main():
         return wav, nfe
 
     def timed(k, w, engine=eng):
+        # engine setup, not warm-up: the first call per shape sizes the workspace (eager), the second
+        # captures the hipGraphs; W warm-up replays follow, then exactly K timed steps
+        for i in range(2):
+            step(-1 - i, engine)
         for i in range(w):
             step(i, engine)
         torch.cuda.synchronize()          # device-wide: drains both pipeline streams

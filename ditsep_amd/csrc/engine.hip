@@ -703,6 +703,7 @@ struct dsn_ctx {
     const float num = (float)(smin * smin) * a * b * (float)ls;
     return sqrtf(num / (float)(th + ls));
   }
+  std::vector<float> t_override;  // scheduled sampler: explicit timesteps (first N used), empty = linspace
   Sched schedule(int N, float t_eps, float snr) const {
     Sched s;
     const double smin = cfg.sde_sigma_min, smax = cfg.sde_sigma_max, ls = log(smax / smin);
@@ -716,6 +717,8 @@ struct dsn_ctx {
     const float stp = N > 1 ? (end - start) / (float)(N - 1) : 0.f;
     const int halfway = N / 2;
     for (int i = 0; i < N; ++i) s.t[i] = i < halfway ? start + stp * (float)i : end - stp * (float)(N - 1 - i);
+    if ((int)t_override.size() >= N)
+      for (int i = 0; i < N; ++i) s.t[i] = t_override[i];
     const float sqdt = sqrtf((float)(1.0 / N));
     for (int i = 0; i < N; ++i) {
       const float t = s.t[i];
@@ -1088,6 +1091,23 @@ int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t see
     if (nfe_out) *nfe_out = N * (corrector_steps + 1);
     HIPCHK(hipGetLastError());
   });
+}
+
+// get_pc_scheduled_sampler (src/sdes/__init__.py:49-130): same loop with caller-provided timesteps
+// (linear / log / revlog grids of N+1 points, the first N are used).  The reference's `dt` stays 1/N in
+// this sampler too (its `getattr(kwargs, "dt", ...)` on a dict never finds the key).
+int dsn_pc_sample_sched(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
+                        int N, const float* timesteps_host, int corrector_steps, float snr, int denoise, int* nfe_out,
+                        void* stream) {
+  if (!ctx || !timesteps_host || N <= 0) return DSN_EINVAL;
+  ctx->t_override.assign(timesteps_host, timesteps_host + N);
+  const bool g = ctx->use_graphs;
+  ctx->use_graphs = false;  // schedules are free-form: not worth a graph cache entry each
+  const int rc = dsn_pc_sample(ctx, y, noise, seed, x_out, B, T, N, corrector_steps, snr, timesteps_host[N - 1], denoise,
+                               nfe_out, stream);
+  ctx->use_graphs = g;
+  ctx->t_override.clear();
+  return rc;
 }
 
 int dsn_hop_length(const dsn_ctx* ctx) { return ctx ? ctx->hop() : DSN_EINVAL; }

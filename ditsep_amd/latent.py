@@ -147,7 +147,10 @@ class LatentDiffSep:
         sde.N = N
         kwargs = {"eps": self.t_eps, "n_spkrs": self.n_src, **kwargs}
         if schedule is not None:
-            raise NotImplementedError("scheduled step sizes (get_pc_scheduled_sampler) are not implemented natively")
+            if minibatch is not None:
+                raise NotImplementedError("minibatch + schedule")
+            return sdes.get_pc_scheduled_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y,
+                                                 schedule=schedule, **kwargs)
         if minibatch is None:
             return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
         M = y.shape[0]

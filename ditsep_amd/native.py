@@ -24,7 +24,7 @@ MAX_VAE_BLOCKS = 8
 
 EXPORTS = [
     "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
-    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_decode", "dsn_encode",
+    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_decode", "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
     "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
@@ -72,6 +72,7 @@ def load_library() -> C.CDLL:
     lib.dsn_score.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp]
     lib.dsn_ouve_schedule.argtypes = [vp, ci, cf, cf, fp, fp, fp, fp, fp, fp]
     lib.dsn_pc_sample.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, cf, cf, ci, C.POINTER(ci), vp]
+    lib.dsn_pc_sample_sched.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, fp, ci, cf, ci, C.POINTER(ci), vp]
     lib.dsn_decode.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.dsn_encode.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, vp]
     lib.dsn_latent_frames.argtypes = [vp, ci]
@@ -190,7 +191,9 @@ class Engine:
         out["std_T"] = stdT.value
         return out
 
-    def pc_sample(self, y, noise=None, *, N=30, corrector_steps=1, snr=0.5, t_eps=0.03, denoise=True, seed=0):
+    def pc_sample(self, y, noise=None, *, N=30, corrector_steps=1, snr=0.5, t_eps=0.03, denoise=True, seed=0,
+                  timesteps=None):
+        """timesteps: optional explicit schedule (>= N floats, host) -> the scheduled sampler."""
         y = _dev32(y, self.device)
         B, _, D, T = y.shape
         if noise is not None:
@@ -198,6 +201,12 @@ class Engine:
             assert tuple(noise.shape) == (1 + N * (corrector_steps + 1), B, self.n_src, D, T), noise.shape
         x = torch.empty((B, self.n_src, D, T), device=self.device, dtype=torch.float32)
         nfe = C.c_int()
+        if timesteps is not None:
+            ts = (C.c_float * N)(*[float(v) for v in list(timesteps)[:N]])
+            self._check(self.lib.dsn_pc_sample_sched(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N, ts,
+                                                     corrector_steps, snr, int(denoise), C.byref(nfe),
+                                                     self._stream()), "dsn_pc_sample_sched")
+            return x, nfe.value
         self._check(self.lib.dsn_pc_sample(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N,
                                            corrector_steps, snr, t_eps, int(denoise), C.byref(nfe),
                                            self._stream()), "dsn_pc_sample")

@@ -118,11 +118,40 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
     c_steps = 0 if corrector_name == "none" else int(corrector_steps)
     counter = {"calls": 0}
 
+    timesteps = kwargs.pop("timesteps", None)
+
     def pc_sampler():
         s = seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,)).item()) + counter["calls"]
         counter["calls"] += 1
         x, nfe = engine.pc_sample(y, noise, N=sde.N, corrector_steps=c_steps, snr=float(snr), t_eps=float(eps),
-                                  denoise=bool(denoise), seed=s)
+                                  denoise=bool(denoise), seed=s, timesteps=timesteps)
         return x, nfe
 
     return pc_sampler
+
+
+def schedule_timesteps(schedule: str, T: float, eps: float, N: int) -> torch.Tensor:
+    """The N+1-point time grids of the reference's scheduled sampler (src/sdes/__init__.py:95-116)."""
+    base = 10
+    if schedule == "linear":
+        return torch.linspace(T, eps, N + 1)
+    if schedule == "log":
+        return torch.logspace(math.log(T) / math.log(base), math.log(eps) / math.log(base), N + 1, base=base)
+    if schedule == "revlog":
+        return torch.logspace(math.log(eps) / math.log(base), math.log(T) / math.log(base), N + 1,
+                              base=base).flip(dims=(0,))
+    raise NotImplementedError(f"Schedule '{schedule}' does not exist")
+
+
+def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, true_mean=None,
+                             eps=3e-2, snr=0.1, corrector_steps=1, probability_flow=False, intermediate=False,
+                             schedule="linear", **kwargs):
+    """Reference signature (src/sdes/__init__.py:49-64).  Runs the same native loop on the schedule's time
+    grid; the step size stays 1/N exactly as in the reference (its `dt` keyword is never picked up).
+    Deviation, stated: the state has n_spkrs sources (the reference samples `y.shape`, i.e. one source,
+    in this sampler, which cannot separate)."""
+    ts = schedule_timesteps(schedule, sde.T, eps, sde.N)
+    return get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=true_mean, denoise=denoise,
+                          eps=float(ts[sde.N - 1]), snr=snr, corrector_steps=corrector_steps,
+                          probability_flow=probability_flow, intermediate=intermediate, timesteps=ts[: sde.N],
+                          **kwargs)

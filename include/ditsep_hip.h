@@ -99,6 +99,13 @@ int dsn_ouve_schedule(const dsn_ctx* ctx, int N, float t_eps, float snr, float* 
 int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
                   int N, int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream);
 
+/* pc_sampler() of sdes.get_pc_scheduled_sampler (src/sdes/__init__.py:49-130): as dsn_pc_sample with
+ * caller-provided timesteps (host array, N entries used: the first N of the reference's N+1-point
+ * linear / log / revlog grid).  State shape is [B,n_src,D,T] (the reference samples y.shape there). */
+int dsn_pc_sample_sched(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
+                        int N, const float* timesteps_host, int corrector_steps, float snr, int denoise, int* nfe_out,
+                        void* stream);
+
 /* LatentDiffSep.decode: est [B,n_src,D,T] -> wav [B,n_src,target_len] (crop of hop*T;
  * target_len <= 0 means hop*T). */
 int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream);

@@ -91,8 +91,10 @@ def pc_sample(
     denoise: bool = True,
     n_spkrs: int = 2,
     intermediate: bool = False,
+    timesteps=None,
 ):
-    """Run the PC sampler with injected noise.
+    """Run the PC sampler with injected noise.  `timesteps` (>= N entries) replaces linspace(1, eps, N):
+    the scheduled sampler of src/sdes/__init__.py:49-130 (dt stays 1/N there as well).
 
     y      [B, 1, D, T]   mixture latent (the OU steady-state mean)
     noise  [1 + N*(corrector_steps+1), B, n_spkrs, D, T] standard normal draws
@@ -110,7 +112,7 @@ def pc_sample(
         std_T = sde.std(ones)
         x = y + next(it) * _bcast(std_T, y)
         x_mean = x
-        timesteps = torch.linspace(1, eps, N)
+        timesteps = torch.linspace(1, eps, N) if timesteps is None else torch.as_tensor(timesteps, dtype=torch.float32)
         im = []
         for i in range(N):
             t = ones * timesteps[i]

@@ -534,3 +534,24 @@ def test_evaluate_harness_records(tmp_path):
     assert s["number"] == 4 and "si_sdr" in s and "runtime" in s
     evaluate.write_results(str(tmp_path / "out.json"), res)
     model.close()
+
+
+@pytest.mark.parametrize("schedule", ["linear", "log", "revlog"])
+def test_scheduled_sampler_vs_oracle(schedule):
+    """get_pc_scheduled_sampler time grids (N+1 points, first N used, dt = 1/N as the reference computes it)."""
+    from ditsep_amd import sdes as nsdes
+
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 32, out_gain=0.005)
+    eng = make_engine(cfg, sd, precision=X3)
+    N = 5
+    ts = nsdes.schedule_timesteps(schedule, 1, 0.03, N)
+    assert ts.shape == (N + 1,) and abs(float(ts[0]) - 1.0) < 1e-6 and abs(float(ts[-1]) - 0.03) < 1e-6
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn((2, 1, 64, 8), generator=g)
+    noise = sampler.draw_noise(4, 1 + N * 2, (2, 2, 64, 8))
+    ref, _ = sampler.pc_sample(odit.DiTScore(sd, cfg), y, noise, sampler.OUVE(N=N), snr=0.5, corrector_steps=1,
+                               timesteps=ts[:N])
+    out, nfe = eng.pc_sample(y, noise, N=N, corrector_steps=1, snr=0.5, timesteps=ts[:N])
+    assert nfe == 2 * N and rel_l2(out, ref) < 1e-4
+    eng.close()
