@@ -36,6 +36,28 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   const int nkt = (S + 15) >> 4;
   const int vrows = nkt * 16;
 
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;  // role inside a 16-lane transposed-read group
+  constexpr int KSD = DH / 32;
+  // Short sequences (NKT <= 4) with 64-wide heads are pure latency: issue EVERY global load of the
+  // workgroup's single query tile up front (Q, all K tiles, V staging) so they share one round trip.
+  constexpr bool PREFETCH = (NKT <= 4 && DH == 64);
+  op16x8 pq[P][KSD], pk[PREFETCH ? NKT : 1][P][KSD];
+  if (PREFETCH) {
+    const int qrow0 = min((int)blockIdx.y * 16 + r16, S - 1);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks) {
+        pq[p][ks] = *reinterpret_cast<const op16x8*>(qb + p * ps + qrow0 * rs + ks * 32 + g * 8);
+#pragma unroll
+        for (int kt = 0; kt < (PREFETCH ? NKT : 1); ++kt) {
+          const int krow = min(kt * 16 + r16, S - 1);
+          pk[kt][p][ks] = *reinterpret_cast<const op16x8*>(kb + p * ps + krow * rs + ks * 32 + g * 8);
+        }
+      }
+  }
+
   // stage V (zero beyond S) -- DH/8 lanes x 16 B per token row
   constexpr int CPRV = DH / 8;
   const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -49,21 +71,19 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   }
   __syncthreads();
 
-  const int r16 = lane & 15, g = lane >> 4;
-  const int tq = r16 >> 2, tp = r16 & 3;  // role inside a 16-lane transposed-read group
-
   // one query tile per workgroup (blockIdx.y): short sequences are latency bound, so spread the query
   // tiles over more waves (V is staged redundantly, it is small)
   for (int qt = blockIdx.y; qt < nkt; qt += gridDim.y) {
     // ---- scores^T = K Q^T -------------------------------------------------
     const int qrow = min(qt * 16 + r16, S - 1);
-    constexpr int KSD = DH / 32;
     op16x8 fq[P][KSD];
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int ks = 0; ks < KSD; ++ks)
-        fq[p][ks] = *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
+        fq[p][ks] = (PREFETCH && qt == (int)blockIdx.y)
+                        ? pq[p][ks]
+                        : *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
     f32x4 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -75,7 +95,8 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
           op16x8 fk[P];
 #pragma unroll
           for (int p = 0; p < P; ++p)
-            fk[p] = *reinterpret_cast<const op16x8*>(kb + p * ps + krow * rs + ks * 32 + g * 8);
+            fk[p] = PREFETCH ? pk[PREFETCH ? kt : 0][p][ks]
+                             : *reinterpret_cast<const op16x8*>(kb + p * ps + krow * rs + ks * 32 + g * 8);
           if (P == 2) {
             sc[kt] = mfma16<F16>(fk[P - 1], fq[0][ks], sc[kt]);
             sc[kt] = mfma16<F16>(fk[0], fq[P - 1][ks], sc[kt]);

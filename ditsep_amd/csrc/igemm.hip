@@ -18,6 +18,9 @@
 // 16-byte slots of the 256-byte bank row.
 #include "igemm.h"
 
+#ifndef DSN_SETPRIO
+#define DSN_SETPRIO 0
+#endif
 #ifndef DSN_DBG_MODE
 #define DSN_DBG_MODE 0  // development ablation builds: 1 = no in-loop staging, 2 = no MFMAs
 #endif
@@ -518,6 +521,9 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
           fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * TBK + coff);
         }
       }
+#if DSN_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
@@ -529,6 +535,9 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
           acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
         }
       }
+#if DSN_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
   epilogue_tile<P, F16>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);

@@ -22,9 +22,6 @@ void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* s
                          float theta, float dt, float G, int B, int n, int D, int T, hipStream_t s);
 
 // ---- DiT pieces ---------------------------------------------------------------
-// LayerNorm over the last dim (bias optional), fp32 in -> operand planes out
-void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, op16_t* out, long ps,
-                             int planes, int rows, int D, float eps, hipStream_t s);
 // x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a
 // plain copy to operand planes.  D <= 4096, D % 4 == 0.
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
@@ -33,11 +30,6 @@ void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_str
 // FourierFeatures: t[B], w[half] -> planes [B][2*half] = [cos(2 pi t w), sin(2 pi t w)]
 void launch_timestep_features(const float* t, const float* w, int B, int half, op16_t* out, long ps,
                               int planes, hipStream_t s);
-// softmax(q k^T / sqrt(dh)) v with partial rotary embedding applied to q and k.
-// qkv fp32 [B*S][3*H*dh] (q | k | v, head-major inside each), out planes [B*S][H*dh].
-// rope_cos/sin [S][rot] fp32 tables (freqs duplicated over the two halves).
-void launch_attention(const float* qkv, const float* rope_cos, const float* rope_sin, int rot, op16_t* out,
-                      long ps, int planes, int B, int S, int H, int dh, hipStream_t s);
 // MFMA attention over operand planes q|k|v [B*S][3*H*64] written by the fused QKV epilogue
 // (attention.hip); S <= 256.
 int launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, int dh,

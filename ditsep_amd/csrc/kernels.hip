@@ -1,6 +1,6 @@
 // Non-GEMM kernels of the separation path for gfx950: layout transforms, the
-// predictor-corrector elementwise updates, LayerNorm, rotary attention for short
-// latent sequences, Oobleck edge convolutions, Philox RNG and weight packing.
+// predictor-corrector elementwise updates, residual + LayerNorm, Oobleck edge
+// convolutions, SI-SDR sums, Philox RNG and weight packing (attention: attention.hip).
 // All are HBM/LDS-bound byte movers: coalesced 16-byte accesses, wave64 shuffles
 // for reductions, no MFMA.
 #include "kernels.h"
@@ -117,56 +117,6 @@ __global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ LayerNorm
-// one wave per row, float4 per lane per pass
-__global__ void layernorm_planes_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, op16_t* __restrict__ out, long ps,
-                                        int planes, int rows, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * D);
-    const int nv = D >> 2;
-    float s = 0.f;
-    for (int i = lane; i < nv; i += 64) {
-      const f32x4 v = xr[i];
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = wave_sum(s) / D;
-    float q = 0.f;
-    for (int i = lane; i < nv; i += 64) {
-      const f32x4 v = xr[i];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float dlt = v[r] - mean;
-        q += dlt * dlt;
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
-    for (int i = lane; i < nv; i += 64) {
-      const f32x4 v = xr[i];
-      const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (v[r] - mean) * rstd * g[r];
-      if (beta) {
-        const f32x4 bb = reinterpret_cast<const f32x4*>(beta)[i];
-        o += bb;
-      }
-      op16x4 hi, lo;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        op16_t h, l;
-        dsn_split(o[r], h, l, PL_F16(planes));
-        hi[r] = h;
-        lo[r] = l;
-      }
-      const long oi = ((long)row * D >> 2) + i;
-      reinterpret_cast<op16x4*>(out)[oi] = hi;
-      if (PL_COUNT(planes) == 2) reinterpret_cast<op16x4*>(out + ps)[oi] = lo;
-    }
-  }
-}
-
 // Residual-stream update fused with the next LayerNorm: x[row] += bias + sum of the split-K
 // partial slabs of the preceding GEMM (written back when any were added), then LayerNorm
 // (or a plain copy) to operand planes.  One wave per row, the row lives in registers.
@@ -261,89 +211,6 @@ __global__ void rope_tables_kernel(float* __restrict__ ct, float* __restrict__ s
     const float f = (float)p * inv;
     ct[i] = cosf(f);
     st[i] = sinf(f);
-  }
-}
-
-// ------------------------------------------------------------------ attention
-// One workgroup per (batch item, head); K (rotary applied) and V of the whole
-// sequence live in LDS (S <= 256); each wave owns one query at a time: lane = key
-// for q.k^T (K rows padded to DH+4 floats -> conflict-free ds_read_b128), wave
-// shuffles for the softmax statistics, lane = feature for P.V.
-template <int DH>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
-                                                        const float* __restrict__ rcos,
-                                                        const float* __restrict__ rsin, int rot,
-                                                        op16_t* __restrict__ out, long ps, int planes, int S,
-                                                        int H) {
-  static_assert(DH == 64, "lane = feature mapping assumes 64-wide heads");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int KS = DH + 4;
-  float* Ks = smem;           // [S][KS]
-  float* Vs = smem + S * KS;  // [S][DH]
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int Dm = H * DH;
-  const long rowstride = 3L * Dm;
-  const float* base = qkv + (long)b * S * rowstride + h * DH;
-  const int half = rot >> 1;
-
-  for (int i = threadIdx.x; i < S * DH; i += blockDim.x) {
-    const int kj = i / DH, d = i - kj * DH;
-    const float* kr = base + (long)kj * rowstride + Dm;
-    float kv = kr[d];
-    if (d < rot) {
-      const float partner = d < half ? -kr[d + half] : kr[d - half];
-      kv = kv * rcos[kj * rot + d] + partner * rsin[kj * rot + d];
-    }
-    Ks[kj * KS + d] = kv;
-    Vs[kj * DH + d] = base[(long)kj * rowstride + 2 * Dm + d];
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const float scale = rsqrtf((float)DH);
-  const int nchunk = (S + 63) >> 6;
-  for (int qi = wave; qi < S; qi += nw) {
-    // q row: lane = feature, rotary via lane exchange, pre-scaled
-    float qv = base[(long)qi * rowstride + lane];
-    {
-      const int pl = lane < half ? lane + half : lane - half;
-      const float pv = __shfl(qv, pl & 63, 64);
-      if (lane < rot) {
-        const float partner = lane < half ? -pv : pv;
-        qv = qv * rcos[qi * rot + lane] + partner * rsin[qi * rot + lane];
-      }
-    }
-    qv *= scale;
-    float m_run = -INFINITY, l_run = 0.f, o_acc = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
-      const int kj = c * 64 + lane;
-      const bool valid = kj < S;
-      const float* krow = Ks + (valid ? kj : 0) * KS;
-      float sdot = 0.f;
-#pragma unroll
-      for (int d4 = 0; d4 < DH / 4; ++d4) {
-        const f32x4 kk = *reinterpret_cast<const f32x4*>(krow + d4 * 4);
-        sdot += kk[0] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 0));
-        sdot += kk[1] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 1));
-        sdot += kk[2] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 2));
-        sdot += kk[3] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d4 * 4 + 3));
-      }
-      const float sv = valid ? sdot : -INFINITY;
-      const float m_new = fmaxf(m_run, wave_max(sv));
-      const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first chunk
-      const float p = valid ? __expf(sv - m_new) : 0.f;
-      l_run = l_run * alpha + wave_sum(p);
-      o_acc *= alpha;
-      const int kmax = min(64, S - c * 64);
-      const float* vcol = Vs + (long)c * 64 * DH + lane;
-      for (int jj = 0; jj < kmax; ++jj) {
-        const float pj = __shfl(p, jj, 64);
-        o_acc += pj * vcol[jj * DH];
-      }
-      m_run = m_new;
-    }
-    const float o = o_acc / l_run;
-    store_planes(out, ps, planes, ((long)b * S + qi) * Dm + h * DH + lane, o);
   }
 }
 
@@ -585,11 +452,6 @@ void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, c
   hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G,
                      n, D, T, total);
 }
-void launch_layernorm_planes(const float* x, const float* gamma, const float* beta, op16_t* out, long ps,
-                             int planes, int rows, int D, float eps, hipStream_t st) {
-  hipLaunchKernelGGL(layernorm_planes_kernel, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, gamma, beta, out, ps,
-                     planes, rows, D, eps);
-}
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
                           float eps, int do_norm, hipStream_t st) {
@@ -607,18 +469,6 @@ void launch_timestep_features(const float* t, const float* w, int B, int half, o
 }
 void launch_rope_tables(float* ct, float* stb, int S, int rot, hipStream_t st) {
   hipLaunchKernelGGL(rope_tables_kernel, dim3(grid_for((long)S * rot)), dim3(TPB), 0, st, ct, stb, S, rot);
-}
-void launch_attention(const float* qkv, const float* rc, const float* rs, int rot, op16_t* out, long ps,
-                      int planes, int B, int S, int H, int dh, hipStream_t st) {
-  (void)dh;
-  const size_t sm = (size_t)S * (64 + 4 + 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<64>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(attention_kernel<64>, dim3(B * H), dim3(TPB), sm, st, qkv, rc, rs, rot, out, ps, planes, S, H);
 }
 void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
                       int ktaps, int apply_tanh, hipStream_t st) {
