@@ -521,6 +521,53 @@ struct dsn_ctx {
                               d.M, d.N, d.Cin, d.taps);
   }
 
+  // fused ResidualUnit (ru_fused.hip) for the 128-channel layers; `in` and `out` planes must differ
+  bool ru_fusable(const ResUnit& r) const {
+    static const bool off = getenv("DSN_NO_FUSED_RU") != nullptr;
+    return !off && r.conv7.taps == 7 && r.conv7.Cin == 128 && r.conv7.N == 128 && r.conv1.taps == 1 &&
+           r.conv1.Cin == 128 && r.conv1.N == 128 && r.dil <= 9;
+  }
+  void run_ru(const ResUnit& r, const op16_t* in, long ps, float* xf, float* out_f32, op16_t* out, const ActP& next,
+              int S, long L, hipStream_t st) {
+    RuDesc d;
+    memset(&d, 0, sizeof d);
+    d.A = in;
+    d.a_ps = ps;
+    d.X = xf;
+    d.W7 = r.conv7.w;
+    d.w7_ps = r.conv7.ps;
+    d.b7 = r.conv7.bias;
+    d.W1 = r.conv1.w;
+    d.w1_ps = r.conv1.ps;
+    d.b1 = r.conv1.bias;
+    d.out_f32 = out_f32;
+    d.out_planes = out;
+    d.out_ps = ps;
+    d.act_mid = r.act2.kind;
+    d.mid_a = r.act2.a;
+    d.mid_b = r.act2.ib;
+    d.act_out = next.kind;
+    d.out_a = next.a;
+    d.out_b = next.ib;
+    d.S = S;
+    d.L = (int)L;
+    d.dil = r.dil;
+    ProfRec pr;
+    if (profiling) {
+      HIPCHK(hipEventCreate(&pr.a));
+      HIPCHK(hipEventCreate(&pr.b));
+      pr.flops = 2.0 * (double)S * (double)L * 128.0 * 128.0 * 8.0;
+      HIPCHK(hipEventRecord(pr.a, st));
+    }
+    hipError_t e = ru_fused_launch(d, PL, st);
+    if (profiling) {
+      HIPCHK(hipEventRecord(pr.b, st));
+      prof.push_back(pr);
+    }
+    if (e != hipSuccess) fail(DSN_EHIP, "fused residual unit launch failed: %s (S=%d L=%ld dil=%d)",
+                              hipGetErrorString(e), S, L, r.dil);
+  }
+
   // ---------------------------------------------------------------- DiT score
   // xt [B,n,Dl,T], t [B], mix [B,1,Dl,T] -> score token-major [B*T][n*Dl] in ws "sc"
   float* dit_forward(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
@@ -827,6 +874,12 @@ struct dsn_ctx {
       }
       for (int j = 0; j < 3; ++j) {
         const ResUnit& r = b.ru[j];
+        const ActP& next = j < 2 ? b.ru[j + 1].act0 : (bi + 1 < dec_blocks.size() ? dec_blocks[bi + 1].act : dec_final_act);
+        if (ru_fusable(r)) {  // pb -> ph, then the two trade places
+          run_ru(r, pb, o_ps, xf, j < 2 ? xf : nullptr, ph, next, S, Lo, st);
+          std::swap(pb, ph);
+          continue;
+        }
         {
           GemmDesc d = base_desc(pb, o_ps, r.conv7, S, (int)Lo, (int)Lo);
           d.tap_dil = r.dil;
@@ -841,14 +894,8 @@ struct dsn_ctx {
           d.resid = xf;
           d.out_planes = pb;
           d.out_ps = o_ps;
-          if (j < 2) {
-            d.out_f32 = xf;
-            set_act(d, b.ru[j + 1].act0);
-          } else if (bi + 1 < dec_blocks.size()) {
-            set_act(d, dec_blocks[bi + 1].act);
-          } else {
-            set_act(d, dec_final_act);
-          }
+          if (j < 2) d.out_f32 = xf;
+          set_act(d, next);
           run(d, st);
         }
       }
@@ -889,6 +936,12 @@ struct dsn_ctx {
       const VaeBlock& b = enc_blocks[bi];
       for (int j = 0; j < 3; ++j) {
         const ResUnit& r = b.ru[j];
+        const ActP& next = j < 2 ? b.ru[j + 1].act0 : b.act;
+        if (ru_fusable(r)) {  // pa -> ph, then the two trade places
+          run_ru(r, pa, a_ps, xf, j < 2 ? xf : nullptr, ph, next, S, l, st);
+          std::swap(pa, ph);
+          continue;
+        }
         {
           GemmDesc d = base_desc(pa, a_ps, r.conv7, S, (int)l, (int)l);
           d.tap_dil = r.dil;
@@ -903,12 +956,8 @@ struct dsn_ctx {
           d.resid = xf;
           d.out_planes = pa;
           d.out_ps = a_ps;
-          if (j < 2) {
-            d.out_f32 = xf;
-            set_act(d, b.ru[j + 1].act0);
-          } else {
-            set_act(d, b.act);
-          }
+          if (j < 2) d.out_f32 = xf;
+          set_act(d, next);
           run(d, st);
         }
       }

@@ -72,3 +72,25 @@ hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nsta
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);
+
+// Fused Oobleck ResidualUnit over 128-channel channels-last sequences (ru_fused.hip):
+//   out = X + conv1x1(act_mid(conv_k7_dil(A) + b7)) + b1 ;  planes(out) carry act_out for the consumer.
+// A / out_planes must not alias (neighbouring workgroups read each other's halo rows); X / out_f32 may.
+struct RuDesc {
+  const op16_t* A;  // act(x) operand planes [S][L][128]
+  long a_ps;
+  const float* X;  // fp32 residual stream [S][L][128]
+  const op16_t* W7;  // [128][7*128] K-major planes
+  long w7_ps;
+  const float* b7;
+  const op16_t* W1;  // [128][128]
+  long w1_ps;
+  const float* b1;
+  float* out_f32;      // may be null
+  op16_t* out_planes;  // may be null
+  long out_ps;
+  int act_mid, act_out;  // DSN_ACT_*
+  const float *mid_a, *mid_b, *out_a, *out_b;  // snake alpha / 1/beta per channel
+  int S, L, dil;
+};
+hipError_t ru_fused_launch(const RuDesc& d, int pl, hipStream_t stream);

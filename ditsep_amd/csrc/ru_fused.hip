@@ -1,0 +1,257 @@
+// Fused Oobleck ResidualUnit for 128-channel layers on gfx950:
+//     x' = x + conv1x1( act( conv_k7_dilated( a ) ) ),   a = act(x) already in operand planes
+// (reference src/stable_audio_tools/models/autoencoders.py:59-82).  These layers (the last two decoder
+// blocks / first two encoder blocks: 128 channels at 32k-65k samples per sequence) are HBM bound when run
+// as two implicit GEMMs: the k7 output makes a round trip through HBM and the activated input is
+// re-staged from L2 once per tap.  Here one workgroup owns 128 consecutive positions of one sequence:
+//   * the activated input tile WITH its dilation halo (128 + 6d rows x 128 ch) is staged into LDS once
+//     (global_load_lds, rows outside the sequence from a zero page) and serves all 7 taps as row-shifted
+//     fragment reads; chunk slot = (chunk + 2*row) & 15 keeps every ds_read_b128 group conflict free for
+//     any row shift;
+//   * only the weights stream through a 3-stage LDS ring (counted vmcnt, one barrier per k-tile);
+//   * the k7 accumulators get bias + activation in registers, are written as operand planes into the
+//     (now dead) input tile region, and feed the 1x1 conv's MFMAs directly;
+//   * epilogue: + bias + fp32 residual -> fp32 x' and act_next(x') planes, 16-byte channels-last stores.
+// HBM bytes per element: read a (planes) + x (4 B), write x' (4 B) + planes -- the intermediate never
+// leaves the CU.
+#include "igemm.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int C = 128;       // channels (compile time)
+constexpr int TL = 128;      // positions per workgroup
+constexpr int KT = 32;       // weight k-tile depth
+constexpr int WTILE = 128 * KT;
+constexpr int NSTW = 3;
+
+__device__ __forceinline__ int swz32(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+
+template <int P, int F16>
+__global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];
+  // [P][AH_ROWS][128]  activated input tile + halo (later: the k7 output tile)  |  [NSTW][P][128][32] weight ring
+  const int halo = 3 * d.dil;
+  const int hrows = (TL + 2 * halo + 3) & ~3;  // multiple of 4 rows = whole glds wave-instructions
+  constexpr int AH_ROWS = TL + 54 + 2;         // max halo (d = 9) rounded up to a multiple of 4
+  constexpr int AH_PLANE = AH_ROWS * C;
+  op16_t* ah = lds;
+  op16_t* ring = lds + P * AH_PLANE;
+  constexpr int RING_STAGE = P * WTILE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_per_seq = (d.L + TL - 1) / TL;
+  const int s = blockIdx.x / tiles_per_seq;
+  const int l0 = (blockIdx.x - s * tiles_per_seq) * TL;
+  const long seq_off = (long)s * d.L * C;
+
+  // ---- 1. stage the input tile + halo: slot q -> (row q/16, slot c' q%16) holds global chunk (c' - 2 row) & 15
+  {
+    const int ninstr = hrows / 4;  // 64 slots = 4 rows per wave-instruction
+    for (int j = wave; j < ninstr; j += 4) {
+      const int q = j * 64 + lane;
+      const int row = q >> 4, cs = q & 15;
+      const int c = (cs - 2 * row) & 15;
+      const int l = l0 - halo + row;
+      const bool ok = l >= 0 && l < d.L;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const op16_t* g = ok ? d.A + p * d.a_ps + seq_off + (long)l * C + c * 8 : zero_page + (lane & 3) * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(ah + p * AH_PLANE + j * 64 * 8), 16,
+                                         0, 0);
+      }
+    }
+  }
+  // ---- weight ring loader: 8 groups of 16 rows per [128][32] tile, 2 groups per wave
+  const int rsub = lane >> 2, cpos = lane & 3;
+  long wrow_off[2];
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int row = (wave * 2 + gi) * 16 + rsub;
+    wrow_off[gi] = (long)row * 0 + (cpos ^ swz32(row, 0)) * 8;  // row term added per matrix (different K strides)
+  }
+  auto issue_w = [&](const op16_t* W, long wps, int ktot, int koff, int stage) {
+    op16_t* sb = ring + stage * RING_STAGE;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int row = (wave * 2 + gi) * 16 + rsub;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(W + p * wps + (long)row * ktot + koff + wrow_off[gi]),
+            (__attribute__((address_space(3))) void*)(sb + p * WTILE + (wave * 2 + gi) * 16 * KT), 16, 0, 0);
+    }
+  };
+  constexpr int G = 2 * P;  // weight glds per wave per k-tile
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int w_frag = (wn * 64 + frow) * KT + swz32(frow, fchunk) * 8;
+
+  // ---- 2. dilated k7 conv: 7 taps x 4 channel chunks of 32
+  constexpr int NKT7 = 7 * (C / KT);
+  issue_w(d.W7, d.w7_ps, 7 * C, 0, 0);
+  issue_w(d.W7, d.w7_ps, 7 * C, KT, 1);
+  for (int i = 0; i < NKT7; ++i) {
+    if (i + 1 < NKT7)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (i + 2 < NKT7) issue_w(d.W7, d.w7_ps, 7 * C, (i + 2) * KT, (i + 2) % NSTW);
+    const int tap = i >> 2, kc = i & 3;
+    const op16_t* wb = ring + (i % NSTW) * RING_STAGE;
+    op16x8 fa[P][4], fw[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = wm * 64 + k * 16 + frow + tap * d.dil;  // halo = 3 dil: tile row t, tap -> t + tap*dil
+        fa[p][k] = *reinterpret_cast<const op16x8*>(ah + p * AH_PLANE + row * C + ((kc * 4 + fchunk + 2 * row) & 15) * 8);
+        fw[p][k] = *reinterpret_cast<const op16x8*>(wb + p * WTILE + w_frag + k * 16 * KT);
+      }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        if (P == 2) {
+          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
+        }
+        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
+      }
+  }
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the input tile: reuse it for the k7 output
+
+  // ---- 3. bias + activation -> operand planes of the intermediate, in LDS (rows 0..127 of `ah`)
+  issue_w(d.W1, d.w1_ps, C, 0, 0);
+  issue_w(d.W1, d.w1_ps, C, KT, 1);
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = wn * 64 + tn * 16 + nq;
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b7 + n);
+      op16x4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = v[r];
+        if (d.act_mid == DSN_ACT_ELU) a = dsn_elu(a);
+        else if (d.act_mid == DSN_ACT_SNAKE) a = dsn_snake(a, d.mid_a[n + r], d.mid_b[n + r]);
+        op16_t h, l;
+        dsn_split(a, h, l, F16);
+        hi[r] = h;
+        lo[r] = l;
+      }
+      const int off = m * C + (((n >> 3) + 2 * m) & 15) * 8 + (n & 7);
+      *reinterpret_cast<op16x4*>(ah + off) = hi;
+      if (P == 2) *reinterpret_cast<op16x4*>(ah + AH_PLANE + off) = lo;
+      acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- 4. 1x1 conv over the LDS-resident intermediate
+  constexpr int NKT1 = C / KT;
+  for (int i = 0; i < NKT1; ++i) {
+    if (i + 1 < NKT1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (i == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the intermediate's ds_writes
+    __builtin_amdgcn_s_barrier();
+    if (i + 2 < NKT1) issue_w(d.W1, d.w1_ps, C, (i + 2) * KT, (i + 2) % NSTW);
+    const op16_t* wb = ring + (i % NSTW) * RING_STAGE;
+    op16x8 fa[P][4], fw[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = wm * 64 + k * 16 + frow;
+        fa[p][k] = *reinterpret_cast<const op16x8*>(ah + p * AH_PLANE + row * C + ((i * 4 + fchunk + 2 * row) & 15) * 8);
+        fw[p][k] = *reinterpret_cast<const op16x8*>(wb + p * WTILE + w_frag + k * 16 * KT);
+      }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        if (P == 2) {
+          acc[tn][tm] = mfma16<F16>(fw[P - 1][tn], fa[0][tm], acc[tn][tm]);
+          acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[P - 1][tm], acc[tn][tm]);
+        }
+        acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
+      }
+  }
+
+  // ---- 5. + bias + residual -> x' (fp32) and act_next(x') planes
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
+    if (l >= d.L) continue;
+    const long rowoff = seq_off + (long)l * C;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = wn * 64 + tn * 16 + nq;
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + *reinterpret_cast<const f32x4*>(d.X + rowoff + n);
+      if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
+      if (d.out_planes) {
+        op16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = v[r];
+          if (d.act_out == DSN_ACT_ELU) a = dsn_elu(a);
+          else if (d.act_out == DSN_ACT_SNAKE) a = dsn_snake(a, d.out_a[n + r], d.out_b[n + r]);
+          op16_t h, lw;
+          dsn_split(a, h, lw, F16);
+          hi[r] = h;
+          lo[r] = lw;
+        }
+        *reinterpret_cast<op16x4*>(d.out_planes + rowoff + n) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + rowoff + n) = lo;
+      }
+    }
+  }
+}
+
+const op16_t* ru_zero_page() {
+  static op16_t* zp = nullptr;
+  if (!zp) {
+    if (hipMalloc((void**)&zp, 4096) != hipSuccess) return nullptr;
+    (void)hipMemset(zp, 0, 4096);
+  }
+  return zp;
+}
+
+template <int P, int F16>
+hipError_t launch_t(const RuDesc& d, hipStream_t st) {
+  const op16_t* zp = ru_zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+  const size_t smem = ((size_t)P * (TL + 56) * C + (size_t)NSTW * P * WTILE) * sizeof(op16_t);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ru_fused_kernel<P, F16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int grid = d.S * ((d.L + TL - 1) / TL);
+  hipLaunchKernelGGL((ru_fused_kernel<P, F16>), dim3(grid), dim3(256), smem, st, d, zp);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ru_fused_launch(const RuDesc& d, int pl, hipStream_t st) {
+  if (d.dil < 1 || d.dil > 9 || d.S <= 0 || d.L <= 0) return hipErrorInvalidValue;
+  const int P = PL_COUNT(pl), f16 = PL_F16(pl);
+  if (P == 1) return f16 ? launch_t<1, 1>(d, st) : launch_t<1, 0>(d, st);
+  return f16 ? launch_t<2, 1>(d, st) : launch_t<2, 0>(d, st);
+}

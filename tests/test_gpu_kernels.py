@@ -175,6 +175,28 @@ def test_encoder_tiny_vs_oracle(act):
     eng.close()
 
 
+@pytest.mark.parametrize("act", ["elu", "snake"])
+@pytest.mark.parametrize("prec,tol", [(X3, 1e-4), (FP16X3, 2e-5), (BF16, 3e-2), (FP16, 4e-3)])
+def test_fused_residual_unit_128ch_vs_oracle(act, prec, tol):
+    """128-channel layers take the fused ResidualUnit kernel (ru_fused.hip): dilations 1/3/9, sequence
+    lengths that are not multiples of the 128-row tile (300 and 600), decoder and encoder."""
+    cfg = ovae.OobleckConfig(channels=128, c_mults=(1, 2), strides=(2, 4), use_snake=(act == "snake"))
+    sd = tiny_vae_weights(cfg, 23)
+    eng = make_engine(vcfg=cfg, vsd=sd, precision=prec, n_src=2)
+    g = torch.Generator().manual_seed(15)
+    est = torch.randn((2, 2, 64, 75), generator=g)
+    ref = ovae.decode_sources(sd, cfg, est, None, "decoder.")
+    out = eng.decode(est)
+    assert out.shape == ref.shape == (2, 2, 600)
+    assert rel_l2(out, ref) < tol
+    mix = 0.3 * torch.randn((3, 1, 600 - 8), generator=g)          # pads by a full hop to 600
+    vn = torch.randn((3, 64, 75), generator=g)
+    refe = ovae.encode_mix(sd, cfg, mix, vn, "encoder.")
+    oute = eng.encode(mix, vn)
+    assert rel_l2(oute, refe) < tol
+    eng.close()
+
+
 # ------------------------------------------------------------------ sampler
 def test_pc_sampler_tiny_dit_vs_oracle():
     cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
