@@ -16,6 +16,7 @@
 // leaves the CU.
 #include "igemm.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -222,6 +223,192 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v2 (single-plane modes): 256 positions per workgroup, 8 waves (4 x 2 of 64 x 64), and the input is
+// streamed per 32-channel chunk -- chunk kc of the haloed tile ([256 + 6d rows][32 ch], double buffered)
+// serves the 7 taps of that chunk, so K runs (chunk, tap) instead of (tap, chunk).  Against v1 this
+// halves the weight traffic L2 -> LDS per position (a weight tile now feeds 256 rows) and shrinks LDS to
+// 80 KB, so two workgroups = 16 waves share a CU and hide each other's barriers and HBM phases.
+//   conv7 phase : [2][384][32] input chunks (48 KB) | [3][128][32] weight ring (24 KB)
+//   1x1 phase   : [256][128] intermediate (64 KB)   | [2][128][32] weight ring (16 KB)
+constexpr int TL2 = 256;
+constexpr int ACH_ROWS = 384;              // 24 glds wave-instructions of 16 rows: 3 per wave
+constexpr int ACH_STAGE = ACH_ROWS * KT;   // elements
+constexpr int RING2_OFF = 2 * ACH_STAGE;   // conv7 weight ring
+constexpr int H_ELEMS = TL2 * C;
+constexpr int LDS2_ELEMS = H_ELEMS + 2 * WTILE;  // 80 KB
+
+template <int F16>
+__global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];
+  const int halo = 3 * d.dil;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_per_seq = (d.L + TL2 - 1) / TL2;
+  const int s = blockIdx.x / tiles_per_seq;
+  const int l0 = (blockIdx.x - s * tiles_per_seq) * TL2;
+  const long seq_off = (long)s * d.L * C;
+  const int nrows = TL2 + 2 * halo;
+
+  // input chunk loader: slot q = (wave*3 + j)*64 + lane -> row q/4, slot q%4 holds channel chunk slot ^ ((row>>1)&3)
+  const op16_t* a_src[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = (wave * 3 + j) * 64 + lane;
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
+    const int l = l0 - halo + row;
+    a_src[j] = (row < nrows && l >= 0 && l < d.L) ? d.A + seq_off + (long)l * C + c * 8 : nullptr;
+  }
+  auto issue_a = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const op16_t* g = a_src[j] ? a_src[j] + kc * KT : zero_page + (lane & 3) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(lds + (kc & 1) * ACH_STAGE +
+                                                                                  (wave * 3 + j) * 64 * 8),
+                                       16, 0, 0);
+    }
+  };
+  // weight tile loader: [128][32], wave w stages rows 16w..16w+15
+  const int rsub = lane >> 2, cpos = lane & 3;
+  const int wrow = wave * 16 + rsub;
+  const int wcol = (cpos ^ swz32(wrow, 0)) * 8;
+  auto issue_w = [&](const op16_t* W, int ktot, int koff, op16_t* stage) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(W + (long)wrow * ktot + koff + wcol),
+        (__attribute__((address_space(3))) void*)(stage + wave * 16 * KT), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int w_frag = (wn * 64 + frow) * KT + swz32(frow, fchunk) * 8;
+  op16_t* ring = lds + RING2_OFF;
+
+  // ---- dilated k7 conv, K order (chunk, tap)
+  issue_a(0);
+  issue_w(d.W7, 7 * C, 0, ring);                   // (kc 0, tap 0)
+  issue_w(d.W7, 7 * C, C, ring + WTILE);           // (kc 0, tap 1)
+  int st = 0;  // ring stage of k-tile i
+  for (int kc = 0; kc < 4; ++kc) {
+    const op16_t* ach = lds + (kc & 1) * ACH_STAGE;
+#pragma unroll
+    for (int tap = 0; tap < 7; ++tap) {
+      // loads newer than weight tile i that may stay in flight: tile i+1, and around tap 1/2 the next chunk
+      if (kc == 3 && tap == 6)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if ((tap == 1 || tap == 2) && kc < 3)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {  // prefetch k-tile i+2, and at tap 0 the next input chunk (its buffer was last read at tile i-1)
+        int t2 = tap + 2, k2 = kc;
+        if (t2 >= 7) { t2 -= 7; ++k2; }
+        int s2 = st + 2;
+        if (s2 >= NSTW) s2 -= NSTW;
+        if (k2 < 4) issue_w(d.W7, 7 * C, t2 * C + k2 * KT, ring + s2 * WTILE);
+        if (tap == 0 && kc < 3) issue_a(kc + 1);
+      }
+      const op16_t* wb = ring + st * WTILE;
+      op16x8 fa[4], fw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = wm * 64 + k * 16 + frow + tap * d.dil;
+        fa[k] = *reinterpret_cast<const op16x8*>(ach + row * KT + ((fchunk ^ ((row >> 1) & 3)) * 8));
+        fw[k] = *reinterpret_cast<const op16x8*>(wb + w_frag + k * 16 * KT);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
+      if (++st == NSTW) st = 0;
+    }
+  }
+  __builtin_amdgcn_s_barrier();  // input chunks + ring are dead: the intermediate takes their place
+
+  // ---- bias + activation -> intermediate planes in LDS
+  op16_t* ring1 = lds + H_ELEMS;
+  issue_w(d.W1, C, 0, ring1);
+  issue_w(d.W1, C, KT, ring1 + WTILE);
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = wn * 64 + tn * 16 + nq;
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b7 + n);
+      op16x4 hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = v[r];
+        if (d.act_mid == DSN_ACT_ELU) a = dsn_elu(a);
+        else if (d.act_mid == DSN_ACT_SNAKE) a = dsn_snake(a, d.mid_a[n + r], d.mid_b[n + r]);
+        op16_t h, l;
+        dsn_split(a, h, l, F16);
+        hi[r] = h;
+      }
+      *reinterpret_cast<op16x4*>(lds + m * C + (((n >> 3) + 2 * m) & 15) * 8 + (n & 7)) = hi;
+      acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- 1x1 conv over the LDS-resident intermediate (2-stage weight ring)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i == 0)
+      asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (i >= 1 && i + 1 < 4) issue_w(d.W1, C, (i + 1) * KT, ring1 + ((i + 1) & 1) * WTILE);
+    const op16_t* wb = ring1 + (i & 1) * WTILE;
+    op16x8 fa[4], fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = wm * 64 + k * 16 + frow;
+      fa[k] = *reinterpret_cast<const op16x8*>(lds + row * C + ((i * 4 + fchunk + 2 * row) & 15) * 8);
+      fw[k] = *reinterpret_cast<const op16x8*>(wb + w_frag + k * 16 * KT);
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
+  }
+
+  // ---- + bias + residual -> x' (fp32) and act_next(x') planes
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
+    if (l >= d.L) continue;
+    const long rowoff = seq_off + (long)l * C;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = wn * 64 + tn * 16 + nq;
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + *reinterpret_cast<const f32x4*>(d.X + rowoff + n);
+      if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
+      if (d.out_planes) {
+        op16x4 hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = v[r];
+          if (d.act_out == DSN_ACT_ELU) a = dsn_elu(a);
+          else if (d.act_out == DSN_ACT_SNAKE) a = dsn_snake(a, d.out_a[n + r], d.out_b[n + r]);
+          op16_t h, lw;
+          dsn_split(a, h, lw, F16);
+          hi[r] = h;
+        }
+        *reinterpret_cast<op16x4*>(d.out_planes + rowoff + n) = hi;
+      }
+    }
+  }
+}
+
 const op16_t* ru_zero_page() {
   static op16_t* zp = nullptr;
   if (!zp) {
@@ -249,9 +436,27 @@ hipError_t launch_t(const RuDesc& d, hipStream_t st) {
 
 }  // namespace
 
+template <int F16>
+hipError_t launch2_t(const RuDesc& d, hipStream_t st) {
+  const op16_t* zp = ru_zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+  const size_t smem = (size_t)LDS2_ELEMS * sizeof(op16_t);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ru_fused2_kernel<F16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int grid = d.S * ((d.L + TL2 - 1) / TL2);
+  hipLaunchKernelGGL((ru_fused2_kernel<F16>), dim3(grid), dim3(512), smem, st, d, zp);
+  return hipGetLastError();
+}
+
 hipError_t ru_fused_launch(const RuDesc& d, int pl, hipStream_t st) {
   if (d.dil < 1 || d.dil > 9 || d.S <= 0 || d.L <= 0) return hipErrorInvalidValue;
   const int P = PL_COUNT(pl), f16 = PL_F16(pl);
+  static const bool v1 = getenv("DSN_RU_V1") != nullptr;
+  if (P == 1 && !v1) return f16 ? launch2_t<1>(d, st) : launch2_t<0>(d, st);
   if (P == 1) return f16 ? launch_t<1, 1>(d, st) : launch_t<1, 0>(d, st);
   return f16 ? launch_t<2, 1>(d, st) : launch_t<2, 0>(d, st);
 }
