@@ -740,7 +740,7 @@ struct dsn_ctx {
 
   // ---------------------------------------------------------------- OUVE scalars
   struct Sched {
-    std::vector<float> t, std, step, gain, G;
+    std::vector<float> t, std, step, gain, G, g;
     float stdT;
   };
   float ouve_std(float t) const {
@@ -759,6 +759,7 @@ struct dsn_ctx {
     s.step.resize(N);
     s.gain.resize(N);
     s.G.resize(N);
+    s.g.resize(N);
     // torch.linspace(1, eps, N) in fp32: step = (end-start)/(N-1); symmetric fill
     const float start = 1.f, end = t_eps;
     const float stp = N > 1 ? (end - start) / (float)(N - 1) : 0.f;
@@ -774,7 +775,8 @@ struct dsn_ctx {
       s.step[i] = q * q * 2.f;
       s.gain[i] = sqrtf(s.step[i] * 2.f);
       const float sigma = (float)smin * powf((float)(smax / smin), t);
-      s.G[i] = sigma * (float)sqrt(2.0 * ls) * sqdt;
+      s.g[i] = sigma * (float)sqrt(2.0 * ls);
+      s.G[i] = s.g[i] * sqdt;
     }
     s.stdT = ouve_std(1.f);
     return s;
@@ -795,30 +797,52 @@ struct dsn_ctx {
     tv_host = ht;
     tv_B = B;
   }
-  float* pc_sample(const float* y, const float* noise, int B, int T, int N, int c, float snr, float t_eps,
-                   int denoise, hipStream_t st) {
+  struct PcOpts {
+    int pred = DSN_PRED_REVERSE_DIFFUSION, corr = DSN_CORR_ALD, c = 1, denoise = 1;
+    float snr = 0.5f, t_eps = 0.03f;
+    const float* prior_mean = nullptr;
+    float* inter = nullptr;
+    long draws(int N) const { return 1 + (long)N * (c + (pred == DSN_PRED_NONE ? 0 : 1)); }
+  };
+  float* pc_sample(const float* y, const float* noise, int B, int T, int N, const PcOpts& o, hipStream_t st) {
     const int n = cfg.n_src, Dl = cfg.latent_dim;
     const long sz = (long)B * n * Dl * T;
     float* x = wsbuf<float>("pc_x", sz);
     float* xm = wsbuf<float>("pc_xm", sz);
     float* tv = wsbuf<float>("pc_t", (long)B * N);
-    const Sched s = schedule(N, t_eps, snr);
+    float* norms = o.corr == DSN_CORR_LANGEVIN ? wsbuf<float>("pc_norms", 2L * B) : nullptr;
+    const Sched s = schedule(N, o.t_eps, o.snr);
     const float dt = (float)(1.0 / N);
     const float* z = noise;
-    launch_pc_prior(y, z, x, s.stdT, B, n, Dl, T, st);
+    launch_pc_prior(o.prior_mean ? o.prior_mean : y, o.prior_mean != nullptr, z, x, s.stdT, B, n, Dl, T, st);
     z += sz;
+    const bool keep_mean = o.inter != nullptr;  // only `intermediate` reads the corrector's x_mean
     for (int i = 0; i < N; ++i) {
       const float* ti = tv + (long)i * B;
-      for (int k = 0; k < c; ++k) {
+      for (int k = 0; k < o.c; ++k) {
         float* sc = score_tokens(x, ti, y, B, T, st);
-        launch_pc_corrector(x, sc, z, s.step[i], s.gain[i], B, n, Dl, T, st);
+        if (norms) {
+          launch_pc_item_norms(sc, (long)n * Dl * T, B, norms, st);
+          launch_pc_item_norms(z, (long)n * Dl * T, B, norms + B, st);
+        }
+        launch_pc_corrector(x, keep_mean ? xm : nullptr, sc, z, s.step[i], s.gain[i], norms, o.snr, B, n, Dl, T, st);
         z += sz;
       }
+      if (o.inter) {  // (xt, xt_mean) as the corrector returned them; c == 0 / a fresh loop: x_mean = x
+        if (o.c == 0) HIPCHK(hipMemcpyAsync(xm, x, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(o.inter + (2L * i) * sz, x, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(o.inter + (2L * i + 1) * sz, xm, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+      }
+      if (o.pred == DSN_PRED_NONE) {  // x, x_mean = x, x
+        if (o.denoise && i == N - 1) HIPCHK(hipMemcpyAsync(xm, x, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+        continue;
+      }
       float* sc = score_tokens(x, ti, y, B, T, st);
-      launch_pc_predictor(x, xm, y, sc, z, cfg.sde_theta, dt, s.G[i], B, n, Dl, T, st);
+      launch_pc_predictor(x, xm, y, sc, z, cfg.sde_theta, dt, s.G[i], s.g[i], o.pred == DSN_PRED_EULER_MARUYAMA, B, n,
+                          Dl, T, st);
       z += sz;
     }
-    return denoise ? xm : x;
+    return o.denoise ? xm : x;
   }
 
   // ---------------------------------------------------------------- decoder
@@ -1110,36 +1134,73 @@ int dsn_ouve_schedule(const dsn_ctx* ctx, int N, float t_eps, float snr, float* 
   return DSN_OK;
 }
 
-int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N,
-                  int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream) {
+int dsn_pc_sample_ex(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
+                     int N, const dsn_sampler_opts* opts, int* nfe_out, void* stream) {
   return guarded(ctx, [&] {
-    if (!y || !x_out || B <= 0 || T <= 0 || N <= 0 || corrector_steps < 0) fail(DSN_EINVAL, "dsn_pc_sample: bad arguments");
+    if (!y || !x_out || !opts || B <= 0 || T <= 0 || N <= 0 || opts->corrector_steps < 0)
+      fail(DSN_EINVAL, "dsn_pc_sample: bad arguments");
+    if (opts->predictor < 0 || opts->predictor > DSN_PRED_NONE || opts->corrector < 0 ||
+        opts->corrector > DSN_CORR_LANGEVIN)
+      fail(DSN_EINVAL, "dsn_pc_sample: unknown predictor %d / corrector %d", opts->predictor, opts->corrector);
+    dsn_ctx::PcOpts o;
+    o.pred = opts->predictor;
+    o.corr = opts->corrector;
+    o.c = opts->corrector_steps;
+    o.denoise = opts->denoise;
+    o.snr = opts->snr;
+    o.t_eps = opts->timesteps ? opts->timesteps[N - 1] : opts->t_eps;
+    o.inter = opts->intermediates;
     hipStream_t caller = (hipStream_t)stream;
     const int n = ctx->cfg.n_src, Dl = ctx->cfg.latent_dim;
     const long ysz = (long)B * Dl * T, sz = ysz * n;
-    const long draws = 1 + (long)N * (corrector_steps + 1);
+    const long draws = o.draws(N);
+    // free-form schedules / intermediates are not worth a graph cache entry each
+    const bool graphs = ctx->use_graphs;
+    if (opts->timesteps) ctx->t_override.assign(opts->timesteps, opts->timesteps + N);
+    if (opts->timesteps || opts->intermediates) ctx->use_graphs = false;
+    struct Restore {
+      dsn_ctx* c;
+      bool g;
+      ~Restore() {
+        c->use_graphs = g;
+        c->t_override.clear();
+      }
+    } restore{ctx, graphs};
     // stable workspace copies of the caller's tensors (graph replay needs fixed pointers)
     float* yb = ctx->wsbuf<float>("pc_y", ysz);
     float* nz = ctx->wsbuf<float>("pc_noise", sz * draws);
-    ctx->upload_timesteps(B, N, t_eps, snr, caller);
+    float* pm = opts->prior_mean ? ctx->wsbuf<float>("pc_prior_mean", sz) : nullptr;
+    o.prior_mean = pm;
+    ctx->upload_timesteps(B, N, o.t_eps, o.snr, caller);
     hipStream_t st = ctx->enter(caller);
     HIPCHK(hipMemcpyAsync(yb, y, sizeof(float) * ysz, hipMemcpyDeviceToDevice, st));
+    if (pm) HIPCHK(hipMemcpyAsync(pm, opts->prior_mean, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
     if (noise)
       HIPCHK(hipMemcpyAsync(nz, noise, sizeof(float) * sz * draws, hipMemcpyDeviceToDevice, st));
     else
       launch_randn(nz, sz * draws, seed, 0, st);
-    char key[160];
-    snprintf(key, sizeof key, "pc:%d:%d:%d:%d:%a:%a:%d", B, T, N, corrector_steps, snr, t_eps, denoise);
+    char key[192];
+    snprintf(key, sizeof key, "pc:%d:%d:%d:%d:%a:%a:%d:%d:%d:%d", B, T, N, o.c, o.snr, o.t_eps, o.denoise, o.pred,
+             o.corr, pm != nullptr);
     float* res = nullptr;
-    ctx->run_graphed(key, st, [&](hipStream_t s2) {
-      res = ctx->pc_sample(yb, nz, B, T, N, corrector_steps, snr, t_eps, denoise, s2);
-    });
-    if (!res) res = ctx->wsbuf<float>(denoise ? "pc_xm" : "pc_x", sz);  // replayed graph: same buffers
+    ctx->run_graphed(key, st, [&](hipStream_t s2) { res = ctx->pc_sample(yb, nz, B, T, N, o, s2); });
+    if (!res) res = ctx->wsbuf<float>(o.denoise ? "pc_xm" : "pc_x", sz);  // replayed graph: same buffers
     HIPCHK(hipMemcpyAsync(x_out, res, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
     ctx->leave(caller, st);
-    if (nfe_out) *nfe_out = N * (corrector_steps + 1);
+    if (nfe_out) *nfe_out = N * (o.c + 1);
     HIPCHK(hipGetLastError());
   });
+}
+
+int dsn_pc_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N,
+                  int corrector_steps, float snr, float t_eps, int denoise, int* nfe_out, void* stream) {
+  dsn_sampler_opts o;
+  memset(&o, 0, sizeof o);
+  o.corrector_steps = corrector_steps;
+  o.snr = snr;
+  o.t_eps = t_eps;
+  o.denoise = denoise;
+  return dsn_pc_sample_ex(ctx, y, noise, seed, x_out, B, T, N, &o, nfe_out, stream);
 }
 
 // get_pc_scheduled_sampler (src/sdes/__init__.py:49-130): same loop with caller-provided timesteps
@@ -1149,14 +1210,13 @@ int dsn_pc_sample_sched(dsn_ctx* ctx, const float* y, const float* noise, uint64
                         int N, const float* timesteps_host, int corrector_steps, float snr, int denoise, int* nfe_out,
                         void* stream) {
   if (!ctx || !timesteps_host || N <= 0) return DSN_EINVAL;
-  ctx->t_override.assign(timesteps_host, timesteps_host + N);
-  const bool g = ctx->use_graphs;
-  ctx->use_graphs = false;  // schedules are free-form: not worth a graph cache entry each
-  const int rc = dsn_pc_sample(ctx, y, noise, seed, x_out, B, T, N, corrector_steps, snr, timesteps_host[N - 1], denoise,
-                               nfe_out, stream);
-  ctx->use_graphs = g;
-  ctx->t_override.clear();
-  return rc;
+  dsn_sampler_opts o;
+  memset(&o, 0, sizeof o);
+  o.corrector_steps = corrector_steps;
+  o.snr = snr;
+  o.denoise = denoise;
+  o.timesteps = timesteps_host;
+  return dsn_pc_sample_ex(ctx, y, noise, seed, x_out, B, T, N, &o, nfe_out, stream);
 }
 
 int dsn_hop_length(const dsn_ctx* ctx) { return ctx ? ctx->hop() : DSN_EINVAL; }

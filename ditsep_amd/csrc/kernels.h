@@ -14,12 +14,16 @@ void launch_to_planes(const float* src, op16_t* dst, long ps, int planes, long n
 
 // ---- predictor-corrector sampler (OUVE; reference layout x[B,n,D,T], y[B,1,D,T]) ----
 // score is token-major [B*T][n*D].
-void launch_pc_prior(const float* y, const float* z, float* x, float stdT, int B, int n, int D, int T,
-                     hipStream_t s);
-void launch_pc_corrector(float* x, const float* score_tok, const float* z, float step, float noise_gain,
-                         int B, int n, int D, int T, hipStream_t s);
+// mean: y [B,1,D,T] (mean_full = 0) or a full prior mean [B,n,D,T] (mean_full = 1)
+void launch_pc_prior(const float* mean, int mean_full, const float* z, float* x, float stdT, int B, int n, int D,
+                     int T, hipStream_t s);
+// norms == null: host scalars (ALD); else [2][B] per-item norms of score and noise (Langevin corrector)
+void launch_pc_corrector(float* x, float* x_mean /*nullable*/, const float* score_tok, const float* z, float step,
+                         float noise_gain, const float* norms, float snr, int B, int n, int D, int T, hipStream_t s);
+void launch_pc_item_norms(const float* a, long per_item, int B, float* out, hipStream_t s);
+// em = 0 reverse diffusion, 1 Euler-Maruyama; G = g sqrt(dt)
 void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* score_tok, const float* z,
-                         float theta, float dt, float G, int B, int n, int D, int T, hipStream_t s);
+                         float theta, float dt, float G, float g, int em, int B, int n, int D, int T, hipStream_t s);
 
 // ---- DiT pieces ---------------------------------------------------------------
 // x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a

@@ -84,33 +84,80 @@ __device__ __forceinline__ PcIdx pc_index(long i, int n, int D, int T) {
   return o;
 }
 
+// mean_full: the prior mean is a full [B,n,D,T] tensor (`true_mean`, sdes/__init__.py:175-176), else y broadcast
 __global__ void pc_prior_kernel(const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ x,
-                                float stdT, int n, int D, int T, long total) {
+                                float stdT, int n, int D, int T, long total, int mean_full) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const PcIdx ix = pc_index(i, n, D, T);
-    x[i] = y[ix.yi] + z[i] * stdT;
+    x[i] = y[mean_full ? i : ix.yi] + z[i] * stdT;
   }
 }
 
-__global__ void pc_corrector_kernel(float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ z,
-                                    float step, float gain, int n, int D, int T, long total) {
+// x_mean = x + step * score ; x = x_mean + gain * z.  ALD passes host scalars (step_dev == null); the Langevin
+// corrector's step comes from the per-item norms: step = 2 (snr * mean|z| / mean|score|)^2 (correctors.py:46-53),
+// every block re-derives the two batch means in the same fixed order.
+__global__ void pc_corrector_kernel(float* __restrict__ x, float* __restrict__ xmean, const float* __restrict__ sc,
+                                    const float* __restrict__ z, float step, float gain,
+                                    const float* __restrict__ norms, int B, float snr, int n, int D, int T,
+                                    long total) {
+  if (norms) {
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+      float gs = 0.f, ns = 0.f;
+      for (int b = 0; b < B; ++b) {
+        gs += norms[b];
+        ns += norms[B + b];
+      }
+      const float q = snr * (ns / (float)B) / (gs / (float)B);
+      sh[0] = q * q * 2.f;
+      sh[1] = sqrtf(sh[0] * 2.f);
+    }
+    __syncthreads();
+    step = sh[0];
+    gain = sh[1];
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const PcIdx ix = pc_index(i, n, D, T);
     const float xm = x[i] + step * sc[ix.si];
+    if (xmean) xmean[i] = xm;
     x[i] = xm + z[i] * gain;
   }
 }
 
+// out[b] = ||a[b, :]||_2 over `per_item` contiguous floats; one workgroup per item, fixed reduction order
+__global__ void pc_item_norm_kernel(const float* __restrict__ a, long per_item, float* __restrict__ out) {
+  const float* p = a + (long)blockIdx.x * per_item;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < per_item; i += blockDim.x) s += p[i] * p[i];
+  s = wave_sum(s);
+  __shared__ float part[16];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    out[blockIdx.x] = sqrtf(t);
+  }
+}
+
+// reverse diffusion (em == 0): x_mean = x - (theta (y-x) dt - G^2 s),            x = x_mean + G z,   G = g sqrt(dt)
+// Euler-Maruyama   (em == 1): x_mean = x + (theta (y-x) - g^2 s) (-dt),          x = x_mean + G z
 __global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ xmean, const float* __restrict__ y,
                                     const float* __restrict__ sc, const float* __restrict__ z, float theta,
-                                    float dt, float G, int n, int D, int T, long total) {
-  const float G2 = G * G;
+                                    float dt, float G, float g, int em, int n, int D, int T, long total) {
+  const float G2 = G * G, g2 = g * g;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const PcIdx ix = pc_index(i, n, D, T);
     const float xv = x[i];
-    const float f = theta * (y[ix.yi] - xv) * dt;
-    const float rev = f - G2 * sc[ix.si];
-    const float xm = xv - rev;
+    float xm;
+    if (em) {
+      const float total_drift = theta * (y[ix.yi] - xv) + (-g2 * sc[ix.si]);
+      xm = xv + total_drift * (-dt);
+    } else {
+      const float f = theta * (y[ix.yi] - xv) * dt;
+      const float rev = f - G2 * sc[ix.si];
+      xm = xv - rev;
+    }
     xmean[i] = xm;
     x[i] = xm + G * z[i];
   }
@@ -435,22 +482,26 @@ void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hip
 void launch_to_planes(const float* src, op16_t* dst, long ps, int planes, long n, hipStream_t st) {
   hipLaunchKernelGGL(to_planes_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, st, src, dst, ps, planes, n / 4);
 }
-void launch_pc_prior(const float* y, const float* z, float* x, float stdT, int B, int n, int D, int T,
-                     hipStream_t st) {
+void launch_pc_prior(const float* mean, int mean_full, const float* z, float* x, float stdT, int B, int n, int D,
+                     int T, hipStream_t st) {
   const long total = (long)B * n * D * T;
-  hipLaunchKernelGGL(pc_prior_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, y, z, x, stdT, n, D, T, total);
+  hipLaunchKernelGGL(pc_prior_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, mean, z, x, stdT, n, D, T, total,
+                     mean_full);
 }
-void launch_pc_corrector(float* x, const float* sc, const float* z, float step, float gain, int B, int n, int D,
-                         int T, hipStream_t st) {
+void launch_pc_corrector(float* x, float* xm, const float* sc, const float* z, float step, float gain,
+                         const float* norms, float snr, int B, int n, int D, int T, hipStream_t st) {
   const long total = (long)B * n * D * T;
-  hipLaunchKernelGGL(pc_corrector_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, sc, z, step, gain, n, D, T,
-                     total);
+  hipLaunchKernelGGL(pc_corrector_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, sc, z, step, gain, norms,
+                     B, snr, n, D, T, total);
+}
+void launch_pc_item_norms(const float* a, long per_item, int B, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(pc_item_norm_kernel, dim3(B), dim3(256), 0, st, a, per_item, out);
 }
 void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, const float* z, float theta,
-                         float dt, float G, int B, int n, int D, int T, hipStream_t st) {
+                         float dt, float G, float g, int em, int B, int n, int D, int T, hipStream_t st) {
   const long total = (long)B * n * D * T;
-  hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G,
-                     n, D, T, total);
+  hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G, g,
+                     em, n, D, T, total);
 }
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,

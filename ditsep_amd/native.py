@@ -24,11 +24,24 @@ MAX_VAE_BLOCKS = 8
 
 EXPORTS = [
     "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
-    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_decode", "dsn_encode",
+    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_decode",
+    "dsn_encode",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
     "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
 ]
+
+
+PREDICTORS = {"reverse_diffusion": 0, "euler_maruyama": 1, "none": 2}
+CORRECTORS = {"ald": 0, "langevin": 1}
+
+
+class DsnSamplerOpts(C.Structure):
+    _fields_ = [
+        ("predictor", C.c_int), ("corrector", C.c_int), ("corrector_steps", C.c_int),
+        ("snr", C.c_float), ("t_eps", C.c_float), ("denoise", C.c_int),
+        ("timesteps", C.POINTER(C.c_float)), ("prior_mean", C.c_void_p), ("intermediates", C.c_void_p),
+    ]
 
 
 class DsnConfig(C.Structure):
@@ -73,6 +86,8 @@ def load_library() -> C.CDLL:
     lib.dsn_ouve_schedule.argtypes = [vp, ci, cf, cf, fp, fp, fp, fp, fp, fp]
     lib.dsn_pc_sample.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, cf, cf, ci, C.POINTER(ci), vp]
     lib.dsn_pc_sample_sched.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, fp, ci, cf, ci, C.POINTER(ci), vp]
+    lib.dsn_pc_sample_ex.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, C.POINTER(DsnSamplerOpts),
+                                     C.POINTER(ci), vp]
     lib.dsn_decode.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.dsn_encode.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, vp]
     lib.dsn_latent_frames.argtypes = [vp, ci]
@@ -192,24 +207,45 @@ class Engine:
         return out
 
     def pc_sample(self, y, noise=None, *, N=30, corrector_steps=1, snr=0.5, t_eps=0.03, denoise=True, seed=0,
-                  timesteps=None):
-        """timesteps: optional explicit schedule (>= N floats, host) -> the scheduled sampler."""
+                  timesteps=None, predictor="reverse_diffusion", corrector="ald", prior_mean=None,
+                  intermediate=False):
+        """timesteps: optional explicit schedule (>= N floats, host) -> the scheduled sampler.
+        predictor / corrector: the reference's registered names (the ones with a native kernel).
+        prior_mean: `true_mean` [B,n,D,T].  intermediate: also return the per-step (x, x_mean) list."""
+        if predictor not in PREDICTORS or corrector not in CORRECTORS:
+            raise NotImplementedError(f"no native kernel for predictor {predictor!r} / corrector {corrector!r}")
         y = _dev32(y, self.device)
         B, _, D, T = y.shape
+        draws = 1 + N * (corrector_steps + (0 if predictor == "none" else 1))
         if noise is not None:
             noise = _dev32(noise, self.device)
-            assert tuple(noise.shape) == (1 + N * (corrector_steps + 1), B, self.n_src, D, T), noise.shape
+            assert tuple(noise.shape) == (draws, B, self.n_src, D, T), noise.shape
         x = torch.empty((B, self.n_src, D, T), device=self.device, dtype=torch.float32)
         nfe = C.c_int()
-        if timesteps is not None:
-            ts = (C.c_float * N)(*[float(v) for v in list(timesteps)[:N]])
+        plain = (predictor == "reverse_diffusion" and corrector == "ald" and prior_mean is None and not intermediate)
+        if plain and timesteps is None:
+            self._check(self.lib.dsn_pc_sample(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N,
+                                               corrector_steps, snr, t_eps, int(denoise), C.byref(nfe),
+                                               self._stream()), "dsn_pc_sample")
+            return x, nfe.value
+        ts = None if timesteps is None else (C.c_float * N)(*[float(v) for v in list(timesteps)[:N]])
+        if plain:
             self._check(self.lib.dsn_pc_sample_sched(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N, ts,
                                                      corrector_steps, snr, int(denoise), C.byref(nfe),
                                                      self._stream()), "dsn_pc_sample_sched")
             return x, nfe.value
-        self._check(self.lib.dsn_pc_sample(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N,
-                                           corrector_steps, snr, t_eps, int(denoise), C.byref(nfe),
-                                           self._stream()), "dsn_pc_sample")
+        pm = None if prior_mean is None else _dev32(prior_mean, self.device)
+        if pm is not None and tuple(pm.shape) != tuple(x.shape):
+            raise ValueError(f"prior_mean must be {tuple(x.shape)}, got {tuple(pm.shape)}")
+        im = (torch.empty((N, 2, B, self.n_src, D, T), device=self.device, dtype=torch.float32)
+              if intermediate else None)
+        o = DsnSamplerOpts(PREDICTORS[predictor], CORRECTORS[corrector], int(corrector_steps), float(snr),
+                           float(t_eps), int(denoise), ts if ts is not None else None,
+                           None if pm is None else pm.data_ptr(), None if im is None else im.data_ptr())
+        self._check(self.lib.dsn_pc_sample_ex(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N, C.byref(o),
+                                              C.byref(nfe), self._stream()), "dsn_pc_sample_ex")
+        if intermediate:
+            return x, nfe.value, [(im[i, 0], im[i, 1]) for i in range(N)]
         return x, nfe.value
 
     def decode(self, est, target_len: Optional[int] = None):

@@ -2,9 +2,10 @@
 
 `get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, ...)` keeps the
 reference signature and closure return (reference src/sdes/__init__.py:133-193) but
-the whole predictor-corrector loop -- prior draw, N x (annealed-Langevin corrector,
-reverse-diffusion predictor), every score-network call -- runs inside the HIP
-engine as one captured launch sequence.  There is no Python loop and no PyTorch
+the whole predictor-corrector loop -- prior draw, N x (corrector, predictor), every
+score-network call -- runs inside the HIP engine as one captured launch sequence.
+Native kernels exist for the predictors reverse_diffusion / euler_maruyama / none and
+the correctors ald / langevin (/ none).  There is no Python loop and no PyTorch
 fallback: combinations the native path does not implement raise NotImplementedError.
 """
 from __future__ import annotations
@@ -63,12 +64,12 @@ class ReverseDiffusionPredictor:
 
 @PredictorRegistry.register("euler_maruyama")
 class EulerMaruyamaPredictor:
-    """Registered name only; not implemented natively ('next')."""
+    """Marker: executed natively (reference src/sdes/predictors.py:39-52)."""
 
 
 @PredictorRegistry.register("none")
 class NonePredictor:
-    pass
+    """Marker: executed natively as 'no predictor step' (reference src/sdes/predictors.py:69-77)."""
 
 
 @CorrectorRegistry.register("ald")
@@ -78,17 +79,20 @@ class AnnealedLangevinDynamics:
 
 @CorrectorRegistry.register("langevin")
 class LangevinCorrector:
-    pass
+    """Marker: executed natively (reference src/sdes/correctors.py:35-55).  Its step size is a batch mean:
+    results depend on which mixtures share a batch (and a rank), exactly as in the reference."""
 
 
 @CorrectorRegistry.register("ald2")
 class AnnealedLangevinDynamics2:
-    pass
+    """Registered name only: needs MixSDE / PriorMixSDE (correctors.py:93-96), which are outside this path."""
 
 
 @CorrectorRegistry.register("none")
 class NoneCorrector:
-    pass
+    """Runs as zero corrector steps.  (In the reference this name cannot be used with get_pc_sampler at all:
+    NoneCorrector.update_fn returns a 1-tuple that the loop's `xt, xt_mean = ...` cannot unpack,
+    correctors.py:132-133 vs __init__.py:181.)"""
 
 
 def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=None, denoise=True, eps=3e-2,
@@ -103,19 +107,20 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
     if engine is None:
         raise NotImplementedError("get_pc_sampler needs a native score model (object with `.engine`); "
                                   "arbitrary Python score functions are not supported (no PyTorch fallback)")
-    if predictor_name != "reverse_diffusion" or corrector_name not in ("ald", "none"):
-        raise NotImplementedError(f"native sampler implements reverse_diffusion + ald (got {predictor_name}, "
-                                  f"{corrector_name})")
+    if corrector_name == "ald2":
+        raise NotImplementedError("ald2 needs MixSDE / PriorMixSDE (reference correctors.py:93-96); the native "
+                                  "sampler implements the OUVE SDE")
     if not isinstance(sde, OUVESDE):
         raise NotImplementedError("native sampler implements the OUVE SDE")
-    if probability_flow or intermediate or true_mean is not None:
-        raise NotImplementedError("probability_flow / intermediate / true_mean are not implemented natively")
+    # probability_flow: accepted and without effect, as in the reference -- Predictor.__init__ keeps the flag but
+    # builds its reverse SDE with sde.reverse(score_fn) (predictors.py:13-18), so the ODE branch is never reached.
     if n_spkrs != engine.n_src:
         raise ValueError(f"n_spkrs={n_spkrs} but the engine was built for {engine.n_src} sources")
     if (abs(sde.theta - engine.cfg.sde_theta) > 1e-6 or abs(sde.sigma_min - engine.cfg.sde_sigma_min) > 1e-6
             or abs(sde.sigma_max - engine.cfg.sde_sigma_max) > 1e-6):
         raise ValueError("sde parameters differ from the ones the engine was built with")
     c_steps = 0 if corrector_name == "none" else int(corrector_steps)
+    corr = "ald" if corrector_name == "none" else corrector_name
     counter = {"calls": 0}
 
     timesteps = kwargs.pop("timesteps", None)
@@ -123,9 +128,9 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
     def pc_sampler():
         s = seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,)).item()) + counter["calls"]
         counter["calls"] += 1
-        x, nfe = engine.pc_sample(y, noise, N=sde.N, corrector_steps=c_steps, snr=float(snr), t_eps=float(eps),
-                                  denoise=bool(denoise), seed=s, timesteps=timesteps)
-        return x, nfe
+        return engine.pc_sample(y, noise, N=sde.N, corrector_steps=c_steps, snr=float(snr), t_eps=float(eps),
+                                denoise=bool(denoise), seed=s, timesteps=timesteps, predictor=predictor_name,
+                                corrector=corr, prior_mean=true_mean, intermediate=bool(intermediate))
 
     return pc_sampler
 

@@ -106,6 +106,29 @@ int dsn_pc_sample_sched(dsn_ctx* ctx, const float* y, const float* noise, uint64
                         int N, const float* timesteps_host, int corrector_steps, float snr, int denoise, int* nfe_out,
                         void* stream);
 
+/* The other registered predictors / correctors of the reference's sampler library, same loop:
+ *   predictor  DSN_PRED_REVERSE_DIFFUSION (predictors.py:55-66) | DSN_PRED_EULER_MARUYAMA (:39-52) |
+ *              DSN_PRED_NONE (:69-77, no score call, no draw)
+ *   corrector  DSN_CORR_ALD (correctors.py:58-84) | DSN_CORR_LANGEVIN (:35-55: one step size per corrector step from
+ *              the batch means of the per-item score / noise norms -- it couples the items of a batch)
+ * noise (or the on-device draw) holds 1 + N*(corrector_steps + (predictor != NONE)) tensors in consumption order.
+ * timesteps: host array of N floats or NULL (= linspace(1, t_eps, N)).  prior_mean: optional [B,n_src,D,T] device
+ * tensor the prior is drawn around instead of y (`true_mean`, sdes/__init__.py:175-176).  intermediates: optional
+ * [N][2][B,n_src,D,T] device buffer receiving (x, x_mean) after each step's corrector (`intermediate=True`).
+ * nfe_out = N*(corrector_steps+1) whatever the predictor, as the reference reports it (__init__.py:186). */
+enum { DSN_PRED_REVERSE_DIFFUSION = 0, DSN_PRED_EULER_MARUYAMA = 1, DSN_PRED_NONE = 2 };
+enum { DSN_CORR_ALD = 0, DSN_CORR_LANGEVIN = 1 };
+typedef struct dsn_sampler_opts {
+  int predictor, corrector, corrector_steps;
+  float snr, t_eps;
+  int denoise;
+  const float* timesteps;
+  const float* prior_mean;
+  float* intermediates;
+} dsn_sampler_opts;
+int dsn_pc_sample_ex(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
+                     int N, const dsn_sampler_opts* opts, int* nfe_out, void* stream);
+
 /* LatentDiffSep.decode: est [B,n_src,D,T] -> wav [B,n_src,target_len] (crop of hop*T;
  * target_len <= 0 means hop*T). */
 int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream);

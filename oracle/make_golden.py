@@ -86,6 +86,33 @@ def gen_sampler_toy(ns):
     save("sampler_toy", **out)
 
 
+SAMPLER_VARIANTS = (  # (predictor, corrector, probability_flow, corrector_steps)
+    ("euler_maruyama", "ald", False, 1), ("reverse_diffusion", "langevin", False, 2),
+    ("euler_maruyama", "langevin", False, 1), ("none", "ald", False, 1), ("none", "langevin", False, 2),
+    ("reverse_diffusion", "ald", True, 1), ("euler_maruyama", "ald", True, 0),
+)
+
+
+def gen_sampler_variants(ns):
+    """The other registered predictors / correctors reachable through get_pc_sampler's names
+    (predictors.py:39-77, correctors.py:35-55) and the (inert) probability_flow flag."""
+    B, n, D, T, N = 2, 2, 64, 8, 10
+    g = torch.Generator().manual_seed(100)
+    y = torch.randn((B, 1, D, T), generator=g)
+    out = {"y": y, "N": N, "eps": 0.03, "snr": 0.5, "seed": 5}
+    ref_sde = ns.OUVESDE(theta=1.5, sigma_min=0.96, sigma_max=10.0, N=N)
+    for pred, corr, pf, c in SAMPLER_VARIANTS:
+        for dn in (True, False):
+            torch.manual_seed(5)
+            smp = ns.sdes.get_pc_sampler(pred, corr, sde=ref_sde, score_fn=toy_score, y=y, eps=0.03, snr=0.5,
+                                         corrector_steps=c, denoise=dn, n_spkrs=n, probability_flow=pf)
+            x, nfe = smp()
+            key = f"{pred}_{corr}_pf{int(pf)}_c{c}_dn{int(dn)}"
+            out["x_" + key] = x
+            out["nfe_" + key] = nfe
+    save("sampler_variants", **out)
+
+
 def gen_dit(ns):
     for tag, n_src, T in (("2spk", 2, 8), ("3spk", 3, 5)):
         cfg = odit.DiTConfig(n_src=n_src, embed_dim=128, depth=2, num_heads=2)
@@ -185,6 +212,7 @@ def main():
     print("generating golden vectors from", rl.REF_ROOT)
     gen_sde_tables(ns)
     gen_sampler_toy(ns)
+    gen_sampler_variants(ns)
     gen_dit(ns)
     gen_vae(ns)
     gen_e2e(ns)

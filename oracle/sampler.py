@@ -7,7 +7,10 @@ Restates, as closed-form tensor algebra with *injected* noise:
   * SDE.discretize (dt is always 1/N)         reference src/sdes/sdes.py:94-108
   * RSDE.discretize                           reference src/sdes/sdes.py:165-173
   * ReverseDiffusionPredictor.update_fn       reference src/sdes/predictors.py:55-66
+  * EulerMaruyamaPredictor / NonePredictor    reference src/sdes/predictors.py:39-52,69-77
   * AnnealedLangevinDynamics.update_fn        reference src/sdes/correctors.py:58-84
+  * LangevinCorrector.update_fn               reference src/sdes/correctors.py:35-55
+  * RSDE.sde / rsde_parts (probability flow)  reference src/sdes/sdes.py:134-163
   * get_pc_sampler -> pc_sampler()            reference src/sdes/__init__.py:133-193
 
 Noise draw order: prior, then per step
@@ -79,6 +82,16 @@ def step_coefficients(sde: OUVE, timesteps: torch.Tensor, snr: float):
     }
 
 
+PREDICTORS = ("reverse_diffusion", "euler_maruyama", "none")
+CORRECTORS = ("ald", "langevin")
+
+
+def noise_draws(N: int, corrector_steps: int, predictor: str = "reverse_diffusion") -> int:
+    """Standard-normal tensors the sampler consumes: prior + per step [corrector draws] + predictor draw
+    (NonePredictor draws nothing, predictors.py:69-77)."""
+    return 1 + N * (corrector_steps + (0 if predictor == "none" else 1))
+
+
 def pc_sample(
     score_fn,
     y: torch.Tensor,
@@ -92,18 +105,29 @@ def pc_sample(
     n_spkrs: int = 2,
     intermediate: bool = False,
     timesteps=None,
+    predictor: str = "reverse_diffusion",
+    corrector: str = "ald",
+    probability_flow: bool = False,
 ):
     """Run the PC sampler with injected noise.  `timesteps` (>= N entries) replaces linspace(1, eps, N):
     the scheduled sampler of src/sdes/__init__.py:49-130 (dt stays 1/N there as well).
 
+    predictor  'reverse_diffusion' (predictors.py:55-66) | 'euler_maruyama' (:39-52) | 'none' (:69-77)
+    corrector  'ald' (correctors.py:58-84) | 'langevin' (:35-55, batch-mean norms)
+    probability_flow  accepted and WITHOUT EFFECT, as in the reference: Predictor.__init__ stores the flag
+               but builds its reverse SDE with `sde.reverse(score_fn)` (predictors.py:13-18), so RSDE's own
+               probability_flow stays False and the ODE branch of sdes.py:140-173 is never taken.
+
     y      [B, 1, D, T]   mixture latent (the OU steady-state mean)
-    noise  [1 + N*(corrector_steps+1), B, n_spkrs, D, T] standard normal draws
+    noise  [noise_draws(N, corrector_steps, predictor), B, n_spkrs, D, T] standard normal draws
     returns (x [B, n_spkrs, D, T], nfe[, intermediates])
     """
+    if predictor not in PREDICTORS or corrector not in CORRECTORS:
+        raise ValueError(f"unknown predictor/corrector {predictor!r}/{corrector!r}")
     N = sde.N
     B = y.shape[0]
     shape = (B, n_spkrs) + tuple(y.shape[2:])
-    assert noise.shape[0] == 1 + N * (corrector_steps + 1), noise.shape
+    assert noise.shape[0] == noise_draws(N, corrector_steps, predictor), noise.shape
     assert tuple(noise.shape[1:]) == shape
     it = iter(noise)
     dt = 1 / N
@@ -116,25 +140,42 @@ def pc_sample(
         im = []
         for i in range(N):
             t = ones * timesteps[i]
-            # corrector: annealed Langevin dynamics
-            std = sde.std(t)
-            for _ in range(corrector_steps):
-                grad = score_fn(x, t, y)
-                z = next(it)
-                step = (snr * std) ** 2 * 2
-                x_mean = x + _bcast(step, x) * grad
-                x = x_mean + z * _bcast(torch.sqrt(step * 2), x)
+            if corrector == "ald":          # annealed Langevin dynamics: step from the kernel std
+                std = sde.std(t)
+                for _ in range(corrector_steps):
+                    grad = score_fn(x, t, y)
+                    z = next(it)
+                    step = (snr * std) ** 2 * 2
+                    x_mean = x + _bcast(step, x) * grad
+                    x = x_mean + z * _bcast(torch.sqrt(step * 2), x)
+            else:                           # langevin: one step size from batch-mean norms
+                for _ in range(corrector_steps):
+                    grad = score_fn(x, t, y)
+                    z = next(it)
+                    grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+                    noise_norm = torch.norm(z.reshape(B, -1), dim=-1).mean()
+                    step = (snr * noise_norm / grad_norm) ** 2 * 2
+                    x_mean = x + step * grad
+                    x = x_mean + z * torch.sqrt(step * 2)
             if intermediate:
                 im.append((x, x_mean))
-            # predictor: reverse diffusion
-            f = sde.theta * (y - x) * dt
-            G = sde.diffusion(t) * torch.sqrt(torch.tensor(dt))
-            rev_f = f - _bcast(G, x) ** 2 * score_fn(x, t, y)
-            z = next(it)
-            x_mean = x - rev_f
-            x = x_mean + _bcast(G, x) * z
+            if predictor == "reverse_diffusion":
+                f = sde.theta * (y - x) * dt
+                G = sde.diffusion(t) * torch.sqrt(torch.tensor(dt))
+                rev_f = f - _bcast(G, x) ** 2 * score_fn(x, t, y)
+                z = next(it)
+                x_mean = x - rev_f
+                x = x_mean + _bcast(G, x) * z
+            elif predictor == "euler_maruyama":
+                z = next(it)
+                g = sde.diffusion(t)
+                total = sde.theta * (y - x) + (-_bcast(g, x) ** 2 * score_fn(x, t, y))
+                x_mean = x + total * (-dt)
+                x = x_mean + _bcast(g, x) * np.sqrt(dt) * z
+            else:
+                x_mean = x
         out = x_mean if denoise else x
-    nfe = N * (corrector_steps + 1)
+    nfe = N * (corrector_steps + 1)        # the reference reports this whatever the predictor (__init__.py:186)
     if intermediate:
         return out, nfe, im
     return out, nfe

@@ -356,8 +356,15 @@ def test_latentdiffsep_facade_matches_oracle(tmp_path):
     assert rel_l2(model.forward(ref["x"], t, ref["y"]), odit.DiTScore(dsd, dcfg)(ref["x"], t, ref["y"])) < 1e-4
     with pytest.raises(ValueError):
         model.get_pc_sampler("bogus", "ald", y)
-    with pytest.raises(NotImplementedError):
-        model.get_pc_sampler("euler_maruyama", "ald", y)
+    with pytest.raises(NotImplementedError):            # needs MixSDE / PriorMixSDE, outside this path
+        model.get_pc_sampler("reverse_diffusion", "ald2", y)
+    # another registered pair through the facade: euler_maruyama + langevin, probability_flow accepted (inert)
+    nz = sampler.draw_noise(9, 1 + 4 * 2, tuple(ref["x"].shape))
+    want, _ = sampler.pc_sample(odit.DiTScore(dsd, dcfg), y.cpu(), nz, sampler.OUVE(N=4), eps=model.t_eps, snr=0.5,
+                                corrector_steps=1, predictor="euler_maruyama", corrector="langevin")
+    got, ns2 = model.get_pc_sampler("euler_maruyama", "langevin", y, N=4, corrector_steps=1, snr=0.5, noise=nz,
+                                    probability_flow=True)()
+    assert ns2 == 8 and rel_l2(got, want) < 1e-4
     model.close()
 
 
@@ -576,4 +583,59 @@ def test_scheduled_sampler_vs_oracle(schedule):
                                timesteps=ts[:N])
     out, nfe = eng.pc_sample(y, noise, N=N, corrector_steps=1, snr=0.5, timesteps=ts[:N])
     assert nfe == 2 * N and rel_l2(out, ref) < 1e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("pred,corr,c", [("euler_maruyama", "ald", 1), ("reverse_diffusion", "langevin", 2),
+                                         ("euler_maruyama", "langevin", 1), ("none", "ald", 1),
+                                         ("none", "langevin", 2), ("euler_maruyama", "ald", 0)])
+def test_sampler_variants_vs_oracle(pred, corr, c):
+    """The other registered predictors / correctors (predictors.py:39-77, correctors.py:35-55) with a real (tiny)
+    DiT score network; the oracle's variants are pinned bit-exact to the reference by
+    tests/golden/sampler_variants.npz."""
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 32, out_gain=0.005)
+    eng = make_engine(cfg, sd, precision=X3)
+    g = torch.Generator().manual_seed(7)
+    B, T, N = 3, 8, 5
+    y = torch.randn((B, 1, 64, T), generator=g)
+    for dn in (True, False):
+        noise = sampler.draw_noise(8, sampler.noise_draws(N, c, pred), (B, 2, 64, T))
+        ref, nfe = sampler.pc_sample(odit.DiTScore(sd, cfg), y, noise, sampler.OUVE(N=N), eps=0.03, snr=0.5,
+                                     corrector_steps=c, denoise=dn, predictor=pred, corrector=corr)
+        out, nfe2 = eng.pc_sample(y, noise, N=N, corrector_steps=c, snr=0.5, t_eps=0.03, denoise=dn, predictor=pred,
+                                  corrector=corr)
+        assert nfe == nfe2 == N * (c + 1)
+        assert rel_l2(out, ref) < 1e-4
+    # device RNG path with the variant (draw count differs for predictor 'none'): finite, right shape
+    out, _ = eng.pc_sample(y, None, N=N, corrector_steps=c, snr=0.5, seed=3, predictor=pred, corrector=corr)
+    assert out.shape == (B, 2, 64, T) and bool(torch.isfinite(out).all())
+    eng.close()
+
+
+def test_sampler_true_mean_and_intermediates_vs_oracle():
+    """`true_mean` (prior drawn around it, sdes/__init__.py:175-176) and `intermediate=True` (per step the
+    corrector's (x, x_mean), :182-183)."""
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 32, out_gain=0.005)
+    eng = make_engine(cfg, sd, precision=X3)
+    g = torch.Generator().manual_seed(17)
+    B, T, N, c = 2, 8, 4, 1
+    y = torch.randn((B, 1, 64, T), generator=g)
+    noise = sampler.draw_noise(18, 1 + N * (c + 1), (B, 2, 64, T))
+    ref, _, im_ref = sampler.pc_sample(odit.DiTScore(sd, cfg), y, noise, sampler.OUVE(N=N), eps=0.03, snr=0.5,
+                                       corrector_steps=c, intermediate=True)
+    out, nfe, im = eng.pc_sample(y, noise, N=N, corrector_steps=c, snr=0.5, t_eps=0.03, intermediate=True)
+    assert nfe == N * (c + 1) and len(im) == N and rel_l2(out, ref) < 1e-4
+    for (a, am), (b, bm) in zip(im, im_ref):
+        assert rel_l2(a, b) < 1e-4 and rel_l2(am, bm) < 1e-4
+    # true_mean: equivalent to moving the prior draw: x_T = true_mean + std(1) z0  (the loop still pulls towards y)
+    tm = torch.randn((B, 2, 64, T), generator=g)
+    std1 = sampler.OUVE(N=N).std(torch.ones(1))
+    shifted = noise.clone()
+    shifted[0] = noise[0] + (tm - y) / std1
+    want, _ = sampler.pc_sample(odit.DiTScore(sd, cfg), y, shifted, sampler.OUVE(N=N), eps=0.03, snr=0.5,
+                                corrector_steps=c)
+    got, _ = eng.pc_sample(y, noise, N=N, corrector_steps=c, snr=0.5, t_eps=0.03, prior_mean=tm)
+    assert rel_l2(got, want) < 1e-4
     eng.close()

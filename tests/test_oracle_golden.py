@@ -8,7 +8,7 @@ import torch
 from oracle import dit as odit
 from oracle import oobleck as ovae
 from oracle import pipeline, sampler
-from oracle.make_golden import checksum, tiny_vae_weights, toy_score, _sub
+from oracle.make_golden import SAMPLER_VARIANTS, checksum, tiny_vae_weights, toy_score, _sub
 
 T = torch.from_numpy
 
@@ -45,6 +45,21 @@ def test_sampler_toy_bit_exact(golden, c, dn):
                                corrector_steps=c, denoise=dn, n_spkrs=2)
     assert nfe == int(g[f"nfe_c{c}_dn{int(dn)}"]) == N * (c + 1)
     assert torch.equal(x, T(g[f"x_c{c}_dn{int(dn)}"]))
+
+
+@pytest.mark.parametrize("pred,corr,pf,c", SAMPLER_VARIANTS)
+@pytest.mark.parametrize("dn", [True, False])
+def test_sampler_variants_bit_exact(golden, pred, corr, pf, c, dn):
+    """Other registered predictors / correctors (euler_maruyama, none, langevin) and the reference's inert
+    probability_flow flag, against vectors produced by the reference's get_pc_sampler."""
+    g = golden("sampler_variants")
+    N = int(g["N"])
+    noise = sampler.draw_noise(int(g["seed"]), sampler.noise_draws(N, c, pred), (2, 2, 64, 8))
+    x, nfe = sampler.pc_sample(toy_score, T(g["y"]), noise, sampler.OUVE(N=N), eps=0.03, snr=0.5, corrector_steps=c,
+                               denoise=dn, n_spkrs=2, predictor=pred, corrector=corr, probability_flow=pf)
+    key = f"{pred}_{corr}_pf{int(pf)}_c{c}_dn{int(dn)}"
+    assert nfe == int(g["nfe_" + key]) == N * (c + 1)
+    assert torch.equal(x, T(g["x_" + key]))
 
 
 def test_sampler_three_speakers(golden):
