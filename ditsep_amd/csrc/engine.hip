@@ -333,6 +333,12 @@ struct dsn_ctx {
   }
 
   void finalize(hipStream_t st) {
+    if (!allocs.empty()) {  // weights replaced (e.g. EMA <-> raw parameters): drop the old packing, graphs are stale
+      HIPCHK(hipDeviceSynchronize());
+      for (void* q : allocs) (void)hipFree(q);
+      allocs.clear();
+      ++ws_epoch;
+    }
     const int D = cfg.dit_embed_dim;
     if (cfg.score_kind == DSN_SCORE_DIT) {
       const std::string sp = "score_model.";

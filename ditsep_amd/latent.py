@@ -111,11 +111,59 @@ class LatentDiffSep:
         self._finalized = True
         return self
 
+    # Names of module BUFFERS in the reference's state_dicts (everything else is a parameter); EMA shadow
+    # parameters follow `parameters()` order, i.e. state_dict order with the buffers skipped.
+    BUFFER_SUFFIXES = ("inv_freq", "num_batches_tracked")
+
+    def load_checkpoint(self, ckpt, use_ema: bool = False):
+        """Load a checkpoint written by the reference's training loop (reference src/diffsep_latent.py:341-392):
+        `ckpt["state_dict"]` (`score_model.*`, `vae.*`, weight-norm `weight_g/weight_v`), `ckpt["ema"]`
+        (torch_ema state: `shadow_params` in `parameters()` order -- of the whole module when
+        `ckpt["trainable_vae"]`, else of `score_model` only) and `ckpt["trainable_vae"]`.
+        `ckpt` is that dict or a path; a path is read with `torch.load(..., weights_only=True)` only (nothing
+        in the file is executed; a checkpoint that loader refuses must be re-saved as plain tensors).
+        `use_ema` selects the EMA weights now; `eval(no_ema=...)` switches later (reference :356-388)."""
+        if not isinstance(ckpt, dict):
+            ckpt = torch.load(str(ckpt), map_location="cpu", weights_only=True)
+        if "state_dict" not in ckpt:
+            raise KeyError("checkpoint has no 'state_dict'")
+        raw = dict(ckpt["state_dict"])
+        self._raw_state, self._ema_state = raw, None
+        ema = ckpt.get("ema")
+        if ema is not None:
+            scope = "" if ckpt.get("trainable_vae", False) else "score_model."
+            names = [k for k in raw if k.startswith(scope) and not k.endswith(self.BUFFER_SUFFIXES)]
+            shadow = list(ema["shadow_params"])
+            if len(shadow) != len(names):
+                raise ValueError(f"EMA holds {len(shadow)} tensors but the state_dict has {len(names)} parameters "
+                                 f"under '{scope}*'")
+            for k, v in zip(names, shadow):
+                if tuple(v.shape) != tuple(raw[k].shape):
+                    raise ValueError(f"EMA tensor for {k}: shape {tuple(v.shape)} != {tuple(raw[k].shape)}")
+            self._ema_state = {**raw, **dict(zip(names, shadow))}
+        if use_ema and self._ema_state is None:
+            raise ValueError("use_ema=True but the checkpoint has no 'ema' entry")   # reference: _error_loading_ema
+        self._using_ema = bool(use_ema)
+        return self.load_state_dict(self._ema_state if use_ema else raw)
+
     def to(self, device):
         return self
 
-    def eval(self, no_ema: bool = True):
+    def train(self, mode: bool = True, no_ema: bool = False):
+        """Reference semantics (src/diffsep_latent.py:356-388): eval mode swaps the EMA weights in unless
+        `no_ema`; train mode restores the raw parameters.  Only meaningful after `load_checkpoint` with an
+        'ema' entry; otherwise a no-op (as the reference behaves when the EMA failed to load)."""
+        ema_state = getattr(self, "_ema_state", None)
+        if ema_state is None:
+            return self
+        want = (not mode) and (not no_ema)
+        if want != self._using_ema:
+            self._using_ema = want
+            self.load_state_dict(ema_state if want else self._raw_state)
         return self
+
+    def eval(self, no_ema: bool = False):
+        return self.train(False, no_ema=no_ema)
 
     @property
     def hop_length(self) -> int:

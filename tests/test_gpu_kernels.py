@@ -639,3 +639,47 @@ def test_sampler_true_mean_and_intermediates_vs_oracle():
     got, _ = eng.pc_sample(y, noise, N=N, corrector_steps=c, snr=0.5, t_eps=0.03, prior_mean=tm)
     assert rel_l2(got, want) < 1e-4
     eng.close()
+
+
+def test_load_checkpoint_with_ema_selection(tmp_path):
+    """Lightning-style checkpoint of the reference (state_dict + torch_ema 'ema' + 'trainable_vae',
+    diffsep_latent.py:341-392): read from disk with the weights-only loader; eval() swaps the EMA weights in,
+    eval(no_ema=True) / train() the raw ones -- each checked against the oracle with the same weights."""
+    from ditsep_amd import LatentDiffSep
+
+    vcfg = ovae.OobleckConfig(channels=32)
+    vsd = tiny_vae_weights(vcfg, 31)
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    ema_sd = odit.random_dit_weights(dcfg, 77, out_gain=0.005)          # a different set of score weights
+    sd = {"score_model." + k: v for k, v in dsd.items()}
+    sd["score_model.transformer.rotary_pos_emb.inv_freq"] = torch.ones(16)   # a buffer: not among the EMA tensors
+    sd.update({"vae." + k: v for k, v in vsd.items()})
+    ckpt = {"state_dict": sd, "trainable_vae": False,
+            "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": [ema_sd[k] for k in dsd],
+                    "collected_params": None}}
+    path = tmp_path / "last.ckpt"
+    torch.save(ckpt, path)
+    model = LatentDiffSep(_tiny_config(tmp_path), precision="bf16x3")
+    model.load_checkpoint(path)                                          # raw parameters, like evaluate_latent.py
+    g = torch.Generator().manual_seed(5)
+    xt = torch.randn((2, 2, 64, 8), generator=g)
+    mix = torch.randn((2, 1, 64, 8), generator=g)
+    t = torch.tensor([0.7, 0.2])
+    want_raw = odit.DiTScore(dsd, dcfg)(xt, t, mix)
+    want_ema = odit.DiTScore(ema_sd, dcfg)(xt, t, mix)
+    assert rel_l2(want_raw, want_ema) > 0.1
+    assert rel_l2(model.forward(xt, t, mix), want_raw) < 1e-4
+    model.eval()                                                         # EMA weights swapped in (graphs re-captured)
+    assert rel_l2(model.forward(xt, t, mix), want_ema) < 1e-4
+    model.eval(no_ema=True)
+    assert rel_l2(model.forward(xt, t, mix), want_raw) < 1e-4
+    model.eval(); model.train()
+    assert rel_l2(model.forward(xt, t, mix), want_raw) < 1e-4
+    # shape / count mismatches are refused
+    bad = dict(ckpt, ema=dict(ckpt["ema"], shadow_params=ckpt["ema"]["shadow_params"][:-1]))
+    with pytest.raises(ValueError):
+        model.load_checkpoint(bad)
+    with pytest.raises(ValueError):
+        model.load_checkpoint({"state_dict": sd}, use_ema=True)
+    model.close()
