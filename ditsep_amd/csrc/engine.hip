@@ -942,6 +942,11 @@ struct dsn_ctx {
   // ---------------------------------------------------------------- encoder
   // wav [S][L] (L multiple of hop) + noise [S][Dl][T] -> y [S][Dl][T]
   void encode(const float* wav, const float* noise, float* y, int S, int L, hipStream_t st) {
+    float* enc = encode_body(wav, S, L, st);
+    launch_vae_sample(enc, noise, y, S, cfg.latent_dim, L / hop(), st);
+  }
+  // wav [S][L] -> encoder output (mean ++ scale) channels-last [S][L/hop][2*Dl] in ws "enc_out"
+  float* encode_body(const float* wav, int S, int L, hipStream_t st) {
     if (!cfg.vae_has_encoder) fail(DSN_ESTATE, "encoder not configured");
     const int Dl = cfg.latent_dim, c0 = cfg.vae_channels;
     long maxel = (long)S * L * c0;
@@ -1019,7 +1024,77 @@ struct dsn_ctx {
       run(d, st);
     }
     if (enc_out.N != 2 * Dl) fail(DSN_EINVAL, "encoder latent %d != 2*latent_dim %d", enc_out.N, 2 * Dl);
-    launch_vae_sample(enc, noise, y, S, Dl, (int)l, st);
+    return enc;
+  }
+
+  // chunk / paste schedule of AudioAutoencoder.decode_audio / encode_audio (autoencoders.py:596-731), latent frames
+  struct ChunkPaste {
+    int src, t0, t1, c0, c1;
+  };
+  std::vector<ChunkPaste> chunk_plan(int total, int chunk, int overlap) {
+    if (overlap < 0 || chunk <= overlap || total < chunk)
+      fail(DSN_EINVAL, "chunked coding needs 0 <= overlap < chunk_size <= frames (got %d, %d, %d)", overlap, chunk, total);
+    const int hopf = chunk - overlap, ol = overlap / 2;
+    std::vector<int> starts;
+    for (int a = 0; a + chunk <= total; a += hopf) starts.push_back(a);
+    if (starts.back() + chunk != total) starts.push_back(total - chunk);
+    std::vector<ChunkPaste> plan;
+    for (size_t i = 0; i < starts.size(); ++i) {
+      const bool last = i + 1 == starts.size();
+      ChunkPaste c;
+      c.src = starts[i];
+      c.t1 = last ? total : (int)i * hopf + chunk;
+      c.t0 = last ? total - chunk : (int)i * hopf;
+      c.c0 = 0;
+      c.c1 = chunk;
+      if (i > 0) {
+        c.t0 += ol;
+        c.c0 += ol;
+      }
+      if (!last) {
+        c.t1 -= ol;
+        c.c1 -= ol;
+      }
+      plan.push_back(c);
+    }
+    return plan;
+  }
+  // est [S][Dl][T] -> wav [S][hop*T] in ws "dec_long": every chunk is an independent decode of `chunk` frames
+  float* decode_chunked(const float* est, int S, int T, int chunk, int overlap, hipStream_t st) {
+    const int Dl = cfg.latent_dim, h = hop();
+    const auto plan = chunk_plan(T, chunk, overlap);
+    float* zc = wsbuf<float>("dec_chunk_in", (long)S * Dl * chunk);
+    float* out = wsbuf<float>("dec_long", (long)S * h * T);
+    const long Lc = (long)h * chunk, Lt = (long)h * T;
+    for (const auto& c : plan) {
+      HIPCHK(hipMemcpy2DAsync(zc, sizeof(float) * chunk, est + c.src, sizeof(float) * T, sizeof(float) * chunk,
+                              (size_t)S * Dl, hipMemcpyDeviceToDevice, st));
+      char key[64];
+      snprintf(key, sizeof key, "dec:%d:%d", S, chunk);
+      float* w = nullptr;
+      run_graphed(key, st, [&](hipStream_t s2) { w = decode(zc, S, chunk, s2); });
+      if (!w) w = wsbuf<float>("dec_wav", (long)S * Lc);
+      HIPCHK(hipMemcpy2DAsync(out + (long)c.t0 * h, sizeof(float) * Lt, w + (long)c.c0 * h, sizeof(float) * Lc,
+                              sizeof(float) * (size_t)(c.t1 - c.t0) * h, S, hipMemcpyDeviceToDevice, st));
+    }
+    return out;
+  }
+  // wav [S][hop*T] -> stitched encoder output [S][T][2*Dl] in ws "enc_long"
+  float* encode_chunked(const float* wav, int S, int T, int chunk, int overlap, hipStream_t st) {
+    const int h = hop(), E = 2 * cfg.latent_dim;
+    const auto plan = chunk_plan(T, chunk, overlap);
+    float* wc = wsbuf<float>("enc_chunk_in", (long)S * h * chunk);
+    float* out = wsbuf<float>("enc_long", (long)S * T * E);
+    const long Lc = (long)h * chunk, Lt = (long)h * T;
+    for (const auto& c : plan) {
+      HIPCHK(hipMemcpy2DAsync(wc, sizeof(float) * Lc, wav + (long)c.src * h, sizeof(float) * Lt, sizeof(float) * Lc, S,
+                              hipMemcpyDeviceToDevice, st));
+      float* e = encode_body(wc, S, (int)Lc, st);
+      HIPCHK(hipMemcpy2DAsync(out + (long)c.t0 * E, sizeof(float) * (size_t)T * E, e + (long)c.c0 * E,
+                              sizeof(float) * (size_t)chunk * E, sizeof(float) * (size_t)(c.t1 - c.t0) * E, S,
+                              hipMemcpyDeviceToDevice, st));
+    }
+    return out;
   }
 };
 
@@ -1276,6 +1351,51 @@ int dsn_encode(dsn_ctx* ctx, const float* mix, const float* vae_noise, uint64_t 
       vae_noise = nz;
     }
     ctx->encode(padded, vae_noise, y, B, (int)Lp, st);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+int dsn_decode_chunked(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, int chunk_size,
+                       int overlap, void* stream) {
+  return guarded(ctx, [&] {
+    if (!est || !wav || B <= 0 || T <= 0) fail(DSN_EINVAL, "dsn_decode_chunked: bad arguments");
+    hipStream_t caller = (hipStream_t)stream;
+    const int S = B * ctx->cfg.n_src;
+    const long Lfull = (long)ctx->hop() * T;
+    const long Lt = target_len > 0 ? target_len : Lfull;
+    if (Lt > Lfull) fail(DSN_EINVAL, "target_len %ld > decoded length %ld", Lt, Lfull);
+    const long esz = (long)S * ctx->cfg.latent_dim * T;
+    float* eb = ctx->wsbuf<float>("dec_est", esz);
+    hipStream_t st = ctx->enter(caller, 1);
+    HIPCHK(hipMemcpyAsync(eb, est, sizeof(float) * esz, hipMemcpyDeviceToDevice, st));
+    float* w = ctx->decode_chunked(eb, S, T, chunk_size, overlap, st);
+    HIPCHK(hipMemcpy2DAsync(wav, sizeof(float) * Lt, w, sizeof(float) * Lfull, sizeof(float) * Lt, S,
+                            hipMemcpyDeviceToDevice, st));
+    ctx->leave(caller, st, 1);
+  });
+}
+
+int dsn_encode_chunked(dsn_ctx* ctx, const float* mix, const float* vae_noise, uint64_t seed, float* y, int B, int L,
+                       int chunk_size, int overlap, void* stream) {
+  return guarded(ctx, [&] {
+    if (!mix || !y || B <= 0 || L < 0) fail(DSN_EINVAL, "dsn_encode_chunked: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int h = ctx->hop();
+    const int T = dsn_latent_frames(ctx, L);
+    const long Lp = (long)T * h;
+    float* padded = ctx->wsbuf<float>("enc_wav", (long)B * Lp);
+    HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * B * Lp, st));
+    if (L > 0)
+      HIPCHK(hipMemcpy2DAsync(padded, sizeof(float) * Lp, mix, sizeof(float) * L, sizeof(float) * L, B,
+                              hipMemcpyDeviceToDevice, st));
+    const long nsz = (long)B * ctx->cfg.latent_dim * T;
+    if (!vae_noise) {
+      float* nz = ctx->wsbuf<float>("enc_noise", nsz);
+      launch_randn(nz, nsz, seed ^ 0x5851F42D4C957F2DULL, 0, st);
+      vae_noise = nz;
+    }
+    float* enc = ctx->encode_chunked(padded, B, T, chunk_size, overlap, st);
+    launch_vae_sample(enc, vae_noise, y, B, ctx->cfg.latent_dim, T, st);
     HIPCHK(hipGetLastError());
   });
 }

@@ -171,8 +171,8 @@ class LatentDiffSep:
 
     # ------------------------------------------------------------------ reference surface
     @torch.no_grad()
-    def encode(self, mix, target=None, vae_noise=None, seed=0):
-        y = self.engine.encode(mix, vae_noise, seed=seed)
+    def encode(self, mix, target=None, vae_noise=None, seed=0, chunked=False, overlap=32, chunk_size=128):
+        y = self.engine.encode(mix, vae_noise, seed=seed, chunked=chunked, overlap=overlap, chunk_size=chunk_size)
         self.max_len_lat = max(self.max_len_lat, y.shape[-1])
         if target is None:
             return y, None
@@ -181,8 +181,10 @@ class LatentDiffSep:
         return y, t.reshape(B, n, *t.shape[2:])
 
     @torch.no_grad()
-    def decode(self, est, target_dim=None):
-        return self.engine.decode(est, target_dim)
+    def decode(self, est, target_dim=None, chunked=False, overlap=32, chunk_size=128):
+        """reference src/diffsep_latent.py:120-128.  `chunked` / `overlap` / `chunk_size` (latent frames) select
+        the VAE's long-form mode, AudioAutoencoder.decode_audio(..., chunked=True) (autoencoders.py:665-731)."""
+        return self.engine.decode(est, target_dim, chunked=chunked, overlap=overlap, chunk_size=chunk_size)
 
     def forward(self, xt, time, mix):
         return self.engine.score(xt, time, mix)

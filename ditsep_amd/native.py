@@ -25,7 +25,7 @@ MAX_VAE_BLOCKS = 8
 EXPORTS = [
     "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_decode",
-    "dsn_encode",
+    "dsn_encode", "dsn_decode_chunked", "dsn_encode_chunked",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_test_igemm",
     "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
@@ -90,6 +90,8 @@ def load_library() -> C.CDLL:
                                      C.POINTER(ci), vp]
     lib.dsn_decode.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.dsn_encode.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, vp]
+    lib.dsn_decode_chunked.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.dsn_encode_chunked.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, vp]
     lib.dsn_latent_frames.argtypes = [vp, ci]
     lib.dsn_hop_length.argtypes = [vp]
     lib.dsn_separate.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, ci, cf, cf, ci,
@@ -248,17 +250,23 @@ class Engine:
             return x, nfe.value, [(im[i, 0], im[i, 1]) for i in range(N)]
         return x, nfe.value
 
-    def decode(self, est, target_len: Optional[int] = None):
+    def decode(self, est, target_len: Optional[int] = None, chunked: bool = False, overlap: int = 32,
+               chunk_size: int = 128):
+        """chunked / overlap / chunk_size: AudioAutoencoder.decode_audio's long-form mode (latent frames)."""
         est = _dev32(est, self.device)
         B, n, D, T = est.shape
         if n != self.n_src or D != self.latent_dim:
             raise ValueError(f"est must be [B,{self.n_src},{self.latent_dim},T], got {tuple(est.shape)}")
         L = target_len if target_len else self.hop_length * T
         wav = torch.empty((B, n, L), device=self.device, dtype=torch.float32)
-        self._check(self.lib.dsn_decode(self.ctx, _ptr(est), _ptr(wav), B, T, L, self._stream()), "dsn_decode")
+        if chunked:
+            self._check(self.lib.dsn_decode_chunked(self.ctx, _ptr(est), _ptr(wav), B, T, L, int(chunk_size),
+                                                    int(overlap), self._stream()), "dsn_decode_chunked")
+        else:
+            self._check(self.lib.dsn_decode(self.ctx, _ptr(est), _ptr(wav), B, T, L, self._stream()), "dsn_decode")
         return wav
 
-    def encode(self, mix, vae_noise=None, seed=0):
+    def encode(self, mix, vae_noise=None, seed=0, chunked: bool = False, overlap: int = 32, chunk_size: int = 128):
         mix = _dev32(mix, self.device)
         B, _, L = mix.shape
         T = self.latent_frames(L)
@@ -266,8 +274,13 @@ class Engine:
             vae_noise = _dev32(vae_noise, self.device)
             assert tuple(vae_noise.shape) == (B, self.latent_dim, T)
         y = torch.empty((B, 1, self.latent_dim, T), device=self.device, dtype=torch.float32)
-        self._check(self.lib.dsn_encode(self.ctx, _ptr(mix), _ptr(vae_noise), seed, _ptr(y), B, L, self._stream()),
-                    "dsn_encode")
+        if chunked:
+            self._check(self.lib.dsn_encode_chunked(self.ctx, _ptr(mix), _ptr(vae_noise), seed, _ptr(y), B, L,
+                                                    int(chunk_size), int(overlap), self._stream()),
+                        "dsn_encode_chunked")
+        else:
+            self._check(self.lib.dsn_encode(self.ctx, _ptr(mix), _ptr(vae_noise), seed, _ptr(y), B, L,
+                                            self._stream()), "dsn_encode")
         return y
 
     def separate(self, mix, *, vae_noise=None, noise=None, seed=0, target_len=None, N=30, corrector_steps=1,

@@ -133,6 +133,20 @@ int dsn_pc_sample_ex(dsn_ctx* ctx, const float* y, const float* noise, uint64_t 
  * target_len <= 0 means hop*T). */
 int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream);
 
+/* AudioAutoencoder.decode_audio(latents, chunked=True, overlap, chunk_size) (reference
+ * src/stable_audio_tools/models/autoencoders.py:665-731): long-form decode as independent chunks of `chunk_size`
+ * latent frames every chunk_size-overlap frames (plus a final chunk flush with the end), pasted with overlap/2
+ * frames dropped at each interior edge.  Bounds activation memory by the chunk, not the utterance.
+ * T < chunk_size is an error (the reference fails there too). */
+int dsn_decode_chunked(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, int chunk_size,
+                       int overlap, void* stream);
+
+/* AudioAutoencoder.encode_audio(audio, chunked=True, ...) (autoencoders.py:596-663) behind LatentDiffSep.encode's
+ * padding: the encoder output (mean ++ scale) is stitched by the same rule, then sampled once with vae_noise
+ * [B,D,T] (the reference samples every chunk with its own draw before stitching: the same distribution). */
+int dsn_encode_chunked(dsn_ctx* ctx, const float* mix, const float* vae_noise, uint64_t seed, float* y, int B, int L,
+                       int chunk_size, int overlap, void* stream);
+
 /* LatentDiffSep.encode (mixture branch): mix [B,1,L] -> y [B,1,D,T], T = (L + pad)/hop with
  * the reference's pad rule (a full extra hop when L % hop == 0).  vae_noise [B,D,T] or NULL
  * (on-device draw with `seed`). */

@@ -171,6 +171,33 @@ def gen_vae(ns):
              vae_noise=vn, latent=lat, wsum=checksum(sd), seed=21, channels=8)
 
 
+def gen_vae_chunked(ns):
+    """AudioAutoencoder.decode_audio / encode_audio with chunked=True (autoencoders.py:596-731) on the tiny
+    ELU autoencoder, no bottleneck (the stitch rule is what is pinned; sampling is tested elsewhere)."""
+    cfg = ovae.OobleckConfig(channels=8, c_mults=(1, 2), strides=(2, 4))
+    sd = tiny_vae_weights(cfg, 24)
+    enc, dec = _ref_vae(ns, cfg)
+    enc.load_state_dict(_sub(sd, "encoder."))
+    dec.load_state_dict(_sub(sd, "decoder."))
+    ae = ns.AudioAutoencoder(enc, dec, latent_dim=cfg.latent_dim, downsampling_ratio=cfg.hop, sample_rate=16000,
+                             io_channels=1).eval()
+    # encode side: no bottleneck, so the stitched tensor is the raw encoder output (mean ++ scale, 2 x latent_dim)
+    ae_enc = ns.AudioAutoencoder(enc, dec, latent_dim=cfg.enc_latent_dim, downsampling_ratio=cfg.hop,
+                                 sample_rate=16000, io_channels=1).eval()
+    g = torch.Generator().manual_seed(25)
+    z = torch.randn((2, cfg.latent_dim, 45), generator=g)
+    wav = 0.3 * torch.randn((2, 1, 45 * cfg.hop), generator=g)
+    out = {"z": z, "wav_in": wav, "wsum": checksum(sd), "seed": 24}
+    with torch.no_grad():
+        for cs, ov in ((16, 4), (16, 5), (15, 0), (45, 6), (20, 10)):
+            out[f"dec_{cs}_{ov}"] = ae.decode_audio(z, chunked=True, overlap=ov, chunk_size=cs)
+            out[f"enc_{cs}_{ov}"] = ae_enc.encode_audio(wav, chunked=True, overlap=ov, chunk_size=cs)
+    save("vae_chunked", **out)
+
+
+CHUNK_CASES = ((16, 4), (16, 5), (15, 0), (45, 6), (20, 10))
+
+
 def gen_e2e(ns):
     """encode -> PC sampler (DiT score) -> decode, composed from the reference's
     own pieces exactly as LatentDiffSep.separate does (diffsep_latent.py:471-487)."""
@@ -215,6 +242,7 @@ def main():
     gen_sampler_variants(ns)
     gen_dit(ns)
     gen_vae(ns)
+    gen_vae_chunked(ns)
     gen_e2e(ns)
     try:
         from . import make_golden_ncsnpp

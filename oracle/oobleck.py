@@ -111,3 +111,59 @@ def decode_sources(sd, cfg: OobleckConfig, est: torch.Tensor, target_dim=None, p
     B, n, D, T = est.shape
     wav = decoder_forward(sd, cfg, est.reshape(B * n, D, T), prefix).reshape(B, n, -1)
     return wav if target_dim is None else wav[..., :target_dim]
+
+
+# ------------------------------------------------------------------ chunked long-form coding
+def chunk_plan(total: int, chunk_size: int, overlap: int):
+    """The chunk / paste schedule of AudioAutoencoder.decode_audio / encode_audio (reference
+    src/stable_audio_tools/models/autoencoders.py:596-731), in LATENT frames:
+    list of (src_start, dst_start, dst_end, chunk_start, chunk_end).  Chunks of `chunk_size` frames every
+    `chunk_size - overlap`; a final chunk flush with the end if the grid does not land there; each paste drops
+    `overlap // 2` frames at every interior edge.  total < chunk_size is an error in the reference too (its loop
+    variable is never bound)."""
+    if not (0 <= overlap < chunk_size) or total < chunk_size:
+        raise ValueError(f"chunked coding needs 0 <= overlap < chunk_size <= length (got {overlap}, {chunk_size}, {total})")
+    hop = chunk_size - overlap
+    starts = list(range(0, total - chunk_size + 1, hop))
+    if starts[-1] + chunk_size != total:
+        starts.append(total - chunk_size)
+    ol = overlap // 2
+    plan = []
+    for i, a in enumerate(starts):
+        last = i == len(starts) - 1
+        t_end = total if last else i * hop + chunk_size
+        t_start = t_end - chunk_size if last else i * hop
+        c0, c1 = 0, chunk_size
+        if i > 0:
+            t_start += ol
+            c0 += ol
+        if not last:
+            t_end -= ol
+            c1 -= ol
+        plan.append((a, t_start, t_end, c0, c1))
+    return plan
+
+
+def decode_chunked(sd, cfg: OobleckConfig, z: torch.Tensor, chunk_size: int, overlap: int, prefix="decoder."):
+    """decode_audio(latents, chunked=True, overlap, chunk_size): z [S, D, T] -> [S, 1, hop*T]."""
+    S, _, T = z.shape
+    h = cfg.hop
+    out = torch.zeros((S, cfg.io_channels, T * h))
+    for a, t0, t1, c0, c1 in chunk_plan(T, chunk_size, overlap):
+        y = decoder_forward(sd, cfg, z[:, :, a:a + chunk_size], prefix)
+        out[:, :, t0 * h:t1 * h] = y[:, :, c0 * h:c1 * h]
+    return out
+
+
+def encode_chunked(sd, cfg: OobleckConfig, wav: torch.Tensor, chunk_size: int, overlap: int, prefix="encoder."):
+    """encode_audio(audio, chunked=True, ...) up to the bottleneck: wav [S, 1, L] (L multiple of hop) ->
+    encoder output [S, enc_latent_dim, L/hop] stitched by the same rule.  (The reference stitches the SAMPLED
+    latents, each chunk with its own random draw; sampling the stitched mean/scale once is the same law.)"""
+    S, _, L = wav.shape
+    h = cfg.hop
+    T = L // h
+    out = torch.zeros((S, cfg.enc_latent_dim, T))
+    for a, t0, t1, c0, c1 in chunk_plan(T, chunk_size, overlap):
+        y = encoder_forward(sd, cfg, wav[:, :, a * h:(a + chunk_size) * h], prefix)
+        out[:, :, t0:t1] = y[:, :, c0:c1]
+    return out

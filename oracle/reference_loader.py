@@ -95,6 +95,7 @@ def load():
         DiffusionTransformer=dit.DiffusionTransformer,
         OobleckDecoder=autoencoders.OobleckDecoder,
         OobleckEncoder=autoencoders.OobleckEncoder,
+        AudioAutoencoder=autoencoders.AudioAutoencoder,
         VAEBottleneck=bottleneck.VAEBottleneck,
         vae_sample=bottleneck.vae_sample,
     )

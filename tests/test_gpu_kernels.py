@@ -683,3 +683,30 @@ def test_load_checkpoint_with_ema_selection(tmp_path):
     with pytest.raises(ValueError):
         model.load_checkpoint({"state_dict": sd}, use_ema=True)
     model.close()
+
+
+@pytest.mark.parametrize("cs,ov", [(16, 4), (16, 5), (45, 6), (20, 10)])
+def test_chunked_long_form_decode_encode_vs_oracle(cs, ov):
+    """decode_audio / encode_audio(chunked=True) stitch rule (autoencoders.py:596-731); the oracle's restatement
+    is pinned to the reference by tests/golden/vae_chunked.npz."""
+    cfg = ovae.OobleckConfig(channels=32, c_mults=(1, 2), strides=(2, 4))
+    sd = tiny_vae_weights(cfg, 26)
+    eng = make_engine(vcfg=cfg, vsd=sd, precision=X3, n_src=2)
+    g = torch.Generator().manual_seed(27)
+    T = 45
+    est = torch.randn((2, 2, 64, T), generator=g)
+    ref = ovae.decode_chunked(sd, cfg, est.reshape(4, 64, T), cs, ov, "decoder.").reshape(2, 2, -1)
+    out = eng.decode(est, chunked=True, chunk_size=cs, overlap=ov)
+    assert out.shape == ref.shape and rel_l2(out, ref) < 1e-4
+    assert torch.equal(eng.decode(est, 300, chunked=True, chunk_size=cs, overlap=ov).cpu(), out.cpu()[..., :300])
+    if cs == T:      # one chunk == the plain decode
+        assert rel_l2(out, eng.decode(est)) < 1e-6
+    mix = 0.3 * torch.randn((3, 1, T * cfg.hop - 3), generator=g)            # pads to T frames
+    vn = torch.randn((3, 64, T), generator=g)
+    enc = ovae.encode_chunked(sd, cfg, sampler.pad_to_hop(mix, cfg.hop), cs, ov, "encoder.")
+    want = ovae.vae_sample(enc, vn).unsqueeze(1)
+    got = eng.encode(mix, vn, chunked=True, chunk_size=cs, overlap=ov)
+    assert got.shape == want.shape and rel_l2(got, want) < 1e-4
+    with pytest.raises(RuntimeError):
+        eng.decode(est, chunked=True, chunk_size=64, overlap=8)               # shorter than one chunk
+    eng.close()

@@ -8,7 +8,7 @@ import torch
 from oracle import dit as odit
 from oracle import oobleck as ovae
 from oracle import pipeline, sampler
-from oracle.make_golden import SAMPLER_VARIANTS, checksum, tiny_vae_weights, toy_score, _sub
+from oracle.make_golden import CHUNK_CASES, SAMPLER_VARIANTS, checksum, tiny_vae_weights, toy_score, _sub
 
 T = torch.from_numpy
 
@@ -158,3 +158,25 @@ def test_fir_resamplers_match_upfirdn_definition():
     w = k2.flip(0, 1)[None, None].repeat(3, 1, 1, 1)
     ref_dn = torch.nn.functional.conv2d(dn, w, groups=3)[:, :, ::2, ::2]
     torch.testing.assert_close(fir_down(x), ref_dn, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("cs,ov", CHUNK_CASES)
+def test_vae_chunked_stitch(golden, cs, ov):
+    """AudioAutoencoder.decode_audio / encode_audio(chunked=True) of the reference (autoencoders.py:596-731)."""
+    g = golden("vae_chunked")
+    cfg = ovae.OobleckConfig(channels=8, c_mults=(1, 2), strides=(2, 4))
+    sd = tiny_vae_weights(cfg, int(g["seed"]))
+    np.testing.assert_allclose(checksum(sd), g["wsum"], rtol=1e-9)
+    close(ovae.decode_chunked(sd, cfg, T(g["z"]), cs, ov), g[f"dec_{cs}_{ov}"])
+    close(ovae.encode_chunked(sd, cfg, T(g["wav_in"]), cs, ov), g[f"enc_{cs}_{ov}"])
+
+
+def test_vae_chunk_plan_edges():
+    assert ovae.chunk_plan(45, 45, 6) == [(0, 0, 45, 0, 45)]                   # a single chunk: nothing trimmed
+    assert ovae.chunk_plan(32, 16, 0) == [(0, 0, 16, 0, 16), (16, 16, 32, 0, 16)]
+    plan = ovae.chunk_plan(45, 16, 4)                                          # grid 0,12,24 + a final flush chunk
+    assert [p[0] for p in plan] == [0, 12, 24, 29] and plan[-1][1:] == (31, 45, 2, 16)
+    covered = sorted(t for p in plan for t in range(p[1], p[2]))
+    assert covered[0] == 0 and covered[-1] == 44 and set(covered) == set(range(45))
+    with pytest.raises(ValueError):
+        ovae.chunk_plan(10, 16, 4)                                             # shorter than one chunk
