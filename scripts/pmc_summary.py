@@ -1,5 +1,5 @@
 """Aggregate rocprofv3 --pmc counter CSVs (separate FETCH_SIZE / WRITE_SIZE passes over
-scripts/pmc_workload.py) into HBM bytes of the implicit-GEMM kernel per DiT score call and per decode,
+scripts/pmc_workload.py) into HBM bytes of the implicit-GEMM kernels (incl. the fused ResidualUnit) per DiT score call and per decode,
 and write profiles/<tag>.json.  gfx950 corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE
 tallies 64 B per 128-B request of wide coalesced reads -> doubled; WRITE_SIZE exact; both in KiB."""
 import csv, glob, json, sys
@@ -8,12 +8,12 @@ def load(dirname, counter):
     rows = []
     for f in glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and "igemm" in r["Kernel_Name"]:
+            if r.get("Counter_Name") == counter and ("igemm" in r["Kernel_Name"] or "ru_fused" in r["Kernel_Name"]):
                 rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     return [v for _, v in sorted(rows)]
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-n_dec = 36                                   # conv_in + 5 x (convT + 3 x (conv7, conv1))
+n_dec = 30          # conv_in + 5 x convT + 3 blocks x 3 x (conv7, conv1) + 2 blocks x 3 fused ResidualUnits
 n_score = (len(fetch) - n_dec) // 2
 assert len(fetch) == len(write) == 2 * n_score + n_dec, (len(fetch), len(write))
 def hbm(a, b): return (2 * sum(fetch[a:b]) + sum(write[a:b])) * 1024
