@@ -58,7 +58,7 @@ def build_engine(device, precision, dcfg, vcfg, dsd, vsd):
     return eng
 
 
-def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
+def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix, y=None):
     """The CPU restatement of the reference path (oracle/, kind = "port") timed on
     this host: sampler + decode on `n_mix` mixtures of the same workload."""
     from oracle import dit as odit
@@ -70,7 +70,7 @@ def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix):
     torch.set_num_threads(cores)
     T = (L + (vcfg.hop - L % vcfg.hop)) // vcfg.hop
     g = torch.Generator().manual_seed(99)
-    y = torch.randn((n_mix, 1, vcfg.latent_dim, T), generator=g)
+    y = torch.randn((n_mix, 1, vcfg.latent_dim, T), generator=g) if y is None else y.detach().cpu().float()
     noise = osmp.draw_noise(g, 1 + N_STEPS * (CORR + 1), (n_mix, dcfg.n_src, vcfg.latent_dim, T))
     score = odit.DiTScore(dsd, dcfg) if isinstance(dcfg, synthetic.DiTConfig) else oncs.NCSNppScore(dsd, dcfg)
     t0 = time.perf_counter()
@@ -236,15 +236,23 @@ def main():
         if not args.no_cpu_baseline:
             n_cpu = 2
             log("cpu baseline (oracle) ...")
-            cb, y_c, noise_c, wav_c = cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_cpu)
+            # the CPU path starts from the same encoded latents of the first synthetic mixtures
+            cb, y_c, noise_c, wav_c = cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_cpu, y=y[:n_cpu])
             log("cpu baseline done:", cb["value"], "utt/s on", cb["cores"], "threads")
             out["cpu_baseline"] = cb
             # live parity of the native path on the very sample the CPU just computed
             xg, _ = eng.pc_sample(y_c, noise_c, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
             wg = eng.decode(xg, L).cpu()
+            # BASELINE's second metric: |SI-SDR(build, s) - SI-SDR(CPU path, s)| per mixture under PIT against the
+            # synthetic sources s (random-init weights: the absolute SI-SDR means nothing, the delta is the gate)
+            from oracle import metrics as omet
+            sdr_g, _ = eng.si_sdr_pit(src[:n_cpu], wg)
+            sdr_c, _ = omet.si_sdr_pit(src[:n_cpu], wav_c)
             out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": float((wg.double() - wav_c.double()).norm()
                                                                    / wav_c.double().norm()),
-                             "tolerance": 1e-3, "mixtures": n_cpu}
+                             "tolerance": 1e-3,
+                             "si_sdr_delta_db_vs_cpu_fp32": float((sdr_g.mean(-1) - sdr_c).abs().max()),
+                             "si_sdr_tolerance_db": 0.05, "mixtures": n_cpu}
         if not args.no_alt:
             noise = torch.randn((1 + N_STEPS * (CORR + 1), 4, dcfg.n_src, 64, int(y.shape[-1])), device=dev)
             wa = eng.decode(eng.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)

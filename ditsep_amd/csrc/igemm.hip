@@ -488,14 +488,16 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     if (s < nkt) issue(s);
 
   for (int i = 0; i < nkt; ++i) {
-    // tile i has landed once at most the loads of the NST-2 younger tiles are outstanding
+    // tile i has landed once at most the loads of the NST-2 younger tiles are outstanding; lgkmcnt(0): this wave's
+    // fragment reads of tile i-1 have completed (not merely been issued) before the barrier lets another wave's
+    // glds overwrite that stage -- hipcc will otherwise leave reads in flight across the barrier
     const int younger = min(NST - 2, nkt - 1 - i);
     if (NST >= 4 && younger >= 2)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
     else if (NST >= 3 && younger >= 1)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of tile i landed; everyone finished tile i-1
 #if DSN_DBG_MODE != 1
     if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
@@ -655,11 +657,11 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
     const int younger = min(NST - 2, nkt - 1 - i);
     if (NST >= 3 && younger >= 1) {
       if (REM == 0 || wave < REM)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW * P) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW * P) : "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GPW - 1) * P) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GPW - 1) * P) : "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);

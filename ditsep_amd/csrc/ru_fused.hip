@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
   issue_w(d.W7, d.w7_ps, 7 * C, KT, 1);
   for (int i = 0; i < NKT7; ++i) {
     if (i + 1 < NKT7)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (i + 2 < NKT7) issue_w(d.W7, d.w7_ps, 7 * C, (i + 2) * KT, (i + 2) % NSTW);
     const int tap = i >> 2, kc = i & 3;
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
         acc[tn][tm] = mfma16<F16>(fw[0][tn], fa[0][tm], acc[tn][tm]);
       }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done reading the input tile: reuse it for the k7 output
 
   // ---- 3. bias + activation -> operand planes of the intermediate, in LDS (rows 0..127 of `ah`)
@@ -165,10 +166,9 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
   constexpr int NKT1 = C / KT;
   for (int i = 0; i < NKT1; ++i) {
     if (i + 1 < NKT1)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (i == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the intermediate's ds_writes
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (i + 2 < NKT1) issue_w(d.W1, d.w1_ps, C, (i + 2) * KT, (i + 2) % NSTW);
     const op16_t* wb = ring + (i % NSTW) * RING_STAGE;
@@ -298,13 +298,16 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
     const op16_t* ach = lds + (kc & 1) * ACH_STAGE;
 #pragma unroll
     for (int tap = 0; tap < 7; ++tap) {
-      // loads newer than weight tile i that may stay in flight: tile i+1, and around tap 1/2 the next chunk
+      // loads newer than weight tile i that may stay in flight: tile i+1, and around tap 1/2 the next chunk.
+      // lgkmcnt(0): this wave's LDS reads of tile i-1 must have COMPLETED before the barrier releases the other
+      // waves to overwrite that stage (hipcc otherwise parks the last fragment reads of a tile across the barrier
+      // and waits for them after it -- a real race, found as nondeterministic 2e-3 waveform errors).
       if (kc == 3 && tap == 6)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else if ((tap == 1 || tap == 2) && kc < 3)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       {  // prefetch k-tile i+2, and at tap 0 the next input chunk (its buffer was last read at tile i-1)
         int t2 = tap + 2, k2 = kc;
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
       if (++st == NSTW) st = 0;
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // input chunks + ring are dead: the intermediate takes their place
 
   // ---- bias + activation -> intermediate planes in LDS
@@ -362,9 +366,9 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i == 0)
-      asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (i >= 1 && i + 1 < 4) issue_w(d.W1, C, (i + 1) * KT, ring1 + ((i + 1) & 1) * WTILE);
     const op16_t* wb = ring1 + (i & 1) * WTILE;
@@ -455,7 +459,7 @@ hipError_t launch2_t(const RuDesc& d, hipStream_t st) {
 hipError_t ru_fused_launch(const RuDesc& d, int pl, hipStream_t st) {
   if (d.dil < 1 || d.dil > 9 || d.S <= 0 || d.L <= 0) return hipErrorInvalidValue;
   const int P = PL_COUNT(pl), f16 = PL_F16(pl);
-  static const bool v1 = getenv("DSN_RU_V1") != nullptr;
+  const bool v1 = getenv("DSN_RU_V1") != nullptr;  // read per launch: tests flip it inside one process
   if (P == 1 && !v1) return f16 ? launch2_t<1>(d, st) : launch2_t<0>(d, st);
   if (P == 1) return f16 ? launch_t<1, 1>(d, st) : launch_t<1, 0>(d, st);
   return f16 ? launch_t<2, 1>(d, st) : launch_t<2, 0>(d, st);
