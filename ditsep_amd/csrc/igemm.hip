@@ -760,21 +760,25 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
   if (d.cfg_bm > 0) return igemm2_launch_cfg(d, pl, d.cfg_bm, d.cfg_bn, d.cfg_nst, d.cfg_bk, stream);
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
+  auto tiles = [&](int tm, int tn) { return (long)cdiv(d.M, tm) * cdiv(d.N, tn) * std::max(d.ksplit, 1); };
   if (planes == 2) {
     // split (hi,lo) operands: 48 MFMAs per wave per 32-deep k-tile
     if (d.ksplit <= 1 && d.taps * d.Cin <= 256) return igemm_launch(d, pl, stream);  // epilogue-bound 1x1 convs
     if (d.M >= 8192) {
-      if (d.N >= 256) bm = bn = 256;
+      if (d.N >= 256 && tiles(256, 256) >= 256) bm = bn = 256;
     } else if (d.M >= 4096 && d.N >= 4096) {
       bm = 256;
       nst = 3;
     }
-  } else if (d.M >= 8192) {                  // large-M conv stacks
-    if (d.N >= 256) {
+  } else if (d.M >= 8192) {                  // large-M conv stacks: the biggest tile that still fills 256 CUs
+    if (d.N >= 256 && tiles(256, 256) >= 256) {
       bm = bn = 256;
       if (k64) { nst = 2; bk = 64; }
-    } else {
+    } else if (d.N < 256 || tiles(256, 128) >= 256) {   // (NCSN++ level 1: M = 32768, N = 256)
       bm = 256;
+      if (k64 && d.N >= 256) { nst = 2; bk = 64; }
+    } else if (k64) {                                    // (NCSN++ level 2: M = 8192)
+      bk = 64;
     }
   } else if (d.M >= 4096 && d.N >= 4096) {   // ConvTranspose phase GEMMs
     bm = bn = 256;
