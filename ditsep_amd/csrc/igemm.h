@@ -37,6 +37,10 @@ struct GemmDesc {
   int resid_row_elems, resid_off;
   const float* bbias;  // per-(batch item, channel) bias [B][bbias_stride] or null (time-embedding bias)
   int bbias_stride;
+  // GroupNorm statistics of the fp32 output, accumulated by the epilogue (atomics) into gn_stats[B][gn_G][2] =
+  // (sum, sum of squares) per (item, group of gn_cpg channels); needs rows_per_b % 64 == 0.  null = off
+  float* gn_stats;
+  int gn_G, gn_cpg;
   float* out_f32;      // or null
   int f32_op;          // DSN_F32_*
   float out_scale;     // applied after bias + residual

@@ -59,6 +59,9 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
     }
     return;
   }
+  float gs[NT], gss[NT];  // GroupNorm partial sums of this lane's 4 channels per column sub-tile
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) gs[tn] = gss[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
     const int m = mw0 + tm * 16 + (lane & 15);
@@ -99,6 +102,10 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
           v += *reinterpret_cast<const f32x4*>(d.resid + (long)b * d.resid_bstride + (long)j * d.resid_row_elems +
                                                d.resid_off + n);
         v *= d.out_scale;
+        if (d.gn_stats) {
+          gs[tn] += (v[0] + v[1]) + (v[2] + v[3]);
+          gss[tn] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         if (d.out_f32) {
           f32x4 o = v;
           if (d.f32_op == DSN_F32_TANH) {
@@ -157,6 +164,26 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         }
         *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
         if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
+      }
+    }
+  }
+  if (d.gn_stats && mw0 < m_end) {
+    // the wave's rows (a 64-aligned run, rows_per_b % 64 == 0) belong to one item; reduce over the 16 row lanes,
+    // then one atomic pair per (column sub-tile, 4-channel lane group)
+    const int b = mw0 / d.rows_per_b;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      float s = gs[tn], ss = gss[tn];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+      }
+      const int n = nw0 + tn * 16 + nq;
+      if ((lane & 15) == 0 && n < d.N) {
+        float* st = d.gn_stats + ((long)b * d.gn_G + n / d.gn_cpg) * 2;
+        atomicAdd(st, s);
+        atomicAdd(st + 1, ss);
       }
     }
   }
