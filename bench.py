@@ -233,6 +233,23 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        # the same step with the encoder included (the reference times sampler + decode only, so this
+        # is a secondary figure, never `value`)
+        def full_step(i):
+            yy = eng.encode(mix, seed=7 + i)
+            xx, _ = eng.pc_sample(yy, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS, denoise=True,
+                                  seed=5000 + i)
+            return eng.decode(xx, L)
+        for i in range(2):
+            full_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            full_step(2 + i)
+        torch.cuda.synchronize()
+        el_full = time.perf_counter() - t0
+        out["with_encode"] = {"value": round(B * args.steps / el_full, 3), "unit": "utt/s",
+                              "ms_per_step": round(1e3 * el_full / args.steps, 2)}
         if not args.no_cpu_baseline:
             n_cpu = 2
             log("cpu baseline (oracle) ...")
