@@ -110,7 +110,7 @@ struct dsn_ctx {
 
   // DiT
   float* tf_w = nullptr;
-  Packed t1, t2, pre, pin, pout, post;
+  Packed t1, t2, pin, pout;  // pin / pout carry the folded pre/postprocess convs (fold_dit_io)
   std::vector<DitLayer> layers;
   // VAE
   Packed dec_in;
@@ -233,6 +233,57 @@ struct dsn_ctx {
   bool has(const std::string& name) const { return raw.count(name) != 0; }
   float* maybe(const std::string& name) const { return has(name) ? raw.at(name).p : nullptr; }
 
+  std::vector<float> to_host(const std::string& name) const {
+    const DevTensor& t = get(name);
+    std::vector<float> h((size_t)t.numel);
+    HIPCHK(hipMemcpy(h.data(), t.p, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+    return h;
+  }
+  void set_raw(const std::string& name, const std::vector<float>& h, std::vector<long> shape) {
+    auto it = raw.find(name);
+    if (it != raw.end()) {
+      (void)hipFree(it->second.p);
+      raw.erase(it);
+    }
+    DevTensor t;
+    t.shape = std::move(shape);
+    t.numel = (long)h.size();
+    HIPCHK(hipMalloc((void**)&t.p, sizeof(float) * h.size()));
+    HIPCHK(hipMemcpy(t.p, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+    raw[name] = t;
+  }
+  // The DiT wraps its transformer in two residual 1x1 convs without bias (dit.py: preprocess_conv before
+  // project_in, postprocess_conv after project_out).  Both pairs are linear, so they are folded once (fp64 on
+  // the host) into one matrix each:  Win (I + Wpre)  and  (I + Wpost) Wout  -- two small GEMMs less per call.
+  void fold_dit_io(const std::string& sp) {
+    const DevTensor& win = get(sp + "transformer.project_in.weight");
+    const DevTensor& wout = get(sp + "transformer.project_out.weight");
+    const long D = win.shape[0], din = win.numel / D, io = wout.shape[0];
+    if (wout.numel != io * D || get(sp + "preprocess_conv.weight").numel != din * din ||
+        get(sp + "postprocess_conv.weight").numel != io * io)
+      fail(DSN_EINVAL, "DiT: preprocess/project_in/project_out/postprocess shapes do not chain");
+    const std::vector<float> a = to_host(sp + "transformer.project_in.weight"), pre = to_host(sp + "preprocess_conv.weight");
+    const std::vector<float> b = to_host(sp + "transformer.project_out.weight"), post = to_host(sp + "postprocess_conv.weight");
+    std::vector<float> fin((size_t)(D * din)), fout((size_t)(io * D));
+    for (long r = 0; r < D; ++r)
+      for (long c = 0; c < din; ++c) {
+        double acc = a[r * din + c];
+        for (long k = 0; k < din; ++k) acc += (double)a[r * din + k] * (double)pre[k * din + c];
+        fin[r * din + c] = (float)acc;
+      }
+    std::vector<double> row((size_t)D);
+    for (long r = 0; r < io; ++r) {
+      for (long c = 0; c < D; ++c) row[c] = b[r * D + c];
+      for (long k = 0; k < io; ++k) {
+        const double w = post[r * io + k];
+        for (long c = 0; c < D; ++c) row[c] += w * (double)b[k * D + c];
+      }
+      for (long c = 0; c < D; ++c) fout[r * D + c] = (float)row[c];
+    }
+    set_raw(sp + "__project_in_folded", fin, {D, din});
+    set_raw(sp + "__project_out_folded", fout, {io, D});
+  }
+
   Packed pack_linear(const std::string& wname, const std::string& bname, bool swiglu, hipStream_t st) {
     const DevTensor& w = get(wname);
     if (w.shape.size() < 2) fail(DSN_EINVAL, "%s: expected a matrix", wname.c_str());
@@ -347,10 +398,9 @@ struct dsn_ctx {
       tf_w = get(sp + "timestep_features.weight").p;
       t1 = pack_linear(sp + "to_timestep_embed.0.weight", sp + "to_timestep_embed.0.bias", false, st);
       t2 = pack_linear(sp + "to_timestep_embed.2.weight", sp + "to_timestep_embed.2.bias", false, st);
-      pre = pack_linear(sp + "preprocess_conv.weight", "", false, st);
-      post = pack_linear(sp + "postprocess_conv.weight", "", false, st);
-      pin = pack_linear(sp + "transformer.project_in.weight", "", false, st);
-      pout = pack_linear(sp + "transformer.project_out.weight", "", false, st);
+      fold_dit_io(sp);
+      pin = pack_linear(sp + "__project_in_folded", "", false, st);
+      pout = pack_linear(sp + "__project_out_folded", "", false, st);
       layers.resize(cfg.dit_depth);
       for (int i = 0; i < cfg.dit_depth; ++i) {
         const std::string lp = sp + "transformer.layers." + std::to_string(i) + ".";
@@ -581,17 +631,13 @@ struct dsn_ctx {
     const int io = n * Dl, din = io + Dl, S = T + 1;
     const long Mt = (long)B * T, M = (long)B * S;
     if (S > 256) fail(DSN_EINVAL, "DiT attention kernel supports at most 255 latent frames (got T=%d)", T);
-    float* U = wsbuf<float>("dit_U", Mt * din);
     op16_t* Up = wsbuf<op16_t>("dit_Up", Mt * din * P);
-    op16_t* H0 = wsbuf<op16_t>("dit_H0", Mt * din * P);
     float* X = wsbuf<float>("dit_X", M * D);
     op16_t* Ap = wsbuf<op16_t>("dit_Ap", M * D * P);
     op16_t* QKVp = wsbuf<op16_t>("dit_QKVp", M * 3 * D * P);
     op16_t* FF = wsbuf<op16_t>("dit_FF", M * 4 * D * P);
     op16_t* TF = wsbuf<op16_t>("dit_TF", (long)B * 256 * P);
     op16_t* TE = wsbuf<op16_t>("dit_TE", (long)B * D * P);
-    float* O = wsbuf<float>("dit_O", Mt * io);
-    op16_t* Op = wsbuf<op16_t>("dit_Op", Mt * io * P);
     float* SC = wsbuf<float>("sc", Mt * io);
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
     const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
@@ -599,16 +645,9 @@ struct dsn_ctx {
     float* rs = wsbuf<float>("rope_sin_" + std::to_string(S), (long)S * rot);
     if (new_rope) launch_rope_tables(rc, rs, S, rot, st);
 
-    launch_pack_tokens(xt, io, mix, Dl, B, T, U, Up, Mt * din, PL, st);
-    {  // h0 = U Wpre^T + U
-      GemmDesc d = base_desc(Up, Mt * din, pre, B, T, T);
-      d.resid = U;
-      d.out_planes = H0;
-      d.out_ps = Mt * din;
-      run(d, st);
-    }
-    {  // X[b, 1+t] = h0 Win^T
-      GemmDesc d = base_desc(H0, Mt * din, pin, B, T, T);
+    launch_pack_tokens(xt, io, mix, Dl, B, T, nullptr, Up, Mt * din, PL, st);
+    {  // X[b, 1+t] = (U + U Wpre^T) Win^T, one folded matrix (fold_dit_io)
+      GemmDesc d = base_desc(Up, Mt * din, pin, B, T, T);
       d.out_f32 = X;
       d.out_bstride = (long)S * D;
       d.out_off = D;
@@ -717,18 +756,10 @@ struct dsn_ctx {
     // final residual update + planes of X (no norm before project_out)
     launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, PL, (int)M, D, 1e-5f, 0,
                          st);
-    {  // o = X[b, 1+t] Wout^T
+    {  // score = o + o Wpost^T with o = X[b, 1+t] Wout^T, one folded matrix
       GemmDesc d = base_desc(Ap, M * D, pout, B, T, S);
       d.in_pad = -1;
       d.in_bstride = (long)S * D;
-      d.out_f32 = O;
-      d.out_planes = Op;
-      d.out_ps = Mt * io;
-      run(d, st);
-    }
-    {  // score = o Wpost^T + o
-      GemmDesc d = base_desc(Op, Mt * io, post, B, T, T);
-      d.resid = O;
       d.out_f32 = SC;
       run(d, st);
     }
