@@ -7,6 +7,8 @@
 // dst[(b*T + t)*(C0+C1) + c] as fp32 (optional) and as operand planes (optional).
 void launch_pack_tokens(const float* src0, int C0, const float* src1, int C1, int B, int T,
                         float* dst_f32, op16_t* dst_planes, long ps, int planes, hipStream_t s);
+// rows of `width` floats (multiple of 4) into rows `dst_stride` floats apart
+void launch_copy_rows(const float* src, float* dst, int rows, int width, long dst_stride, hipStream_t s);
 // token-major fp32 [B*T][C] -> channel-major [B][C][T]
 void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hipStream_t s);
 // fp32 [n] -> operand planes, optional activation

@@ -38,6 +38,17 @@ __global__ void pack_tokens_kernel(const float* __restrict__ s0, int C0, const f
   }
 }
 
+// dst[r * dst_stride + c] = src[r * width + c]  (width % 4 == 0): the timestep-token rows into the residual stream
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int width4,
+                                 long dst_stride) {
+  const long n = (long)rows * width4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / width4;
+    const int c = (int)(i - r * width4);
+    reinterpret_cast<f32x4*>(dst + r * dst_stride)[c] = reinterpret_cast<const f32x4*>(src + r * (long)width4 * 4)[c];
+  }
+}
+
 __global__ void unpack_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int T) {
   const long n = (long)B * C * T;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -475,6 +486,10 @@ void launch_pack_tokens(const float* s0, int C0, const float* s1, int C1, int B,
   const long n = (long)B * T * (C0 + C1);
   hipLaunchKernelGGL(pack_tokens_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, s0, C0, s1, C1, B, T, df, dp, ps,
                      planes);
+}
+void launch_copy_rows(const float* src, float* dst, int rows, int width, long dst_stride, hipStream_t st) {
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long)rows * (width / 4))), dim3(TPB), 0, st, src, dst, rows,
+                     width / 4, dst_stride);
 }
 void launch_unpack_tokens(const float* src, float* dst, int B, int C, int T, hipStream_t st) {
   hipLaunchKernelGGL(unpack_tokens_kernel, dim3(grid_for((long)B * C * T)), dim3(TPB), 0, st, src, dst, B, C, T);
