@@ -1,5 +1,6 @@
-// MFMA attention for the DiT score network on gfx950 (latent sequences: 33 .. 256 tokens,
-// 64-wide heads).  One wave per (batch item, head).
+// MFMA attention for the score networks on gfx950: 64-wide DiT heads / one 64-256 wide NCSN++ head.  Sequences up
+// to 256 tokens keep every score in registers (attention_mfma_kernel); longer ones walk the keys in blocks with an
+// online softmax (attention_long_kernel).
 //
 // Inputs are the operand planes the fused QKV GEMM epilogue wrote: q (rotary applied,
 // pre-scaled by 1/sqrt(dh)) | k (rotary applied) | v, token-major [B*S][3*D].
@@ -199,9 +200,169 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   }
 }
 
+// Long sequences (more than 256 keys: DiT beyond 255 latent frames, NCSN++ attention beyond 64 frames): the same
+// fragment scheme, but keys are walked in blocks of KBT tiles with an online softmax (running max m, running sum l,
+// accumulator rescaled by exp(m_old - m_new) per block), V staged per block -- registers and LDS no longer grow
+// with S.  One wave per (item, head, 16-query tile).
+template <int P, int F16, int DH>
+__global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __restrict__ qkv, long ps,
+                                                            op16_t* __restrict__ out, long out_ps, int S, int H) {
+  constexpr int KBT = 8;         // key tiles per block
+  constexpr int KB = KBT * 16;   // keys per block
+  extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][KB][DH]
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int D = H * DH;
+  const long rs = 3L * D;
+  const op16_t* qb = qkv + (long)b * S * rs + h * DH;
+  const op16_t* kb = qb + D;
+  const op16_t* vb = qb + 2 * D;
+  const int nqt = (S + 15) >> 4;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tq = r16 >> 2, tp = r16 & 3;
+  constexpr int KSD = DH / 32, NDT = DH / 16, CPRV = DH / 8;
+  const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (int qt = blockIdx.y; qt < nqt; qt += gridDim.y) {
+    const int qrow = min(qt * 16 + r16, S - 1);
+    op16x8 fq[P][KSD];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int ks = 0; ks < KSD; ++ks)
+        fq[p][ks] = *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < S; k0 += KB) {
+      __syncthreads();  // the previous block's V reads are done
+      for (int idx = lane; idx < KB * CPRV; idx += 64) {
+        const int row = idx / CPRV, c = idx % CPRV;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const op16x8 v = k0 + row < S ? *reinterpret_cast<const op16x8*>(vb + p * ps + (long)(k0 + row) * rs + c * 8) : zero8;
+          *reinterpret_cast<op16x8*>(vlds + ((long)p * KB + row) * DH + c * 8) = v;
+        }
+      }
+      __syncthreads();
+      // scores^T of this block
+      f32x4 sc[KBT];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KBT; ++kt) {
+        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int krow = min(k0 + kt * 16 + r16, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          op16x8 fk[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            fk[p] = *reinterpret_cast<const op16x8*>(kb + p * ps + (long)krow * rs + ks * 32 + g * 8);
+          if (P == 2) {
+            sc[kt] = mfma16<F16>(fk[P - 1], fq[0][ks], sc[kt]);
+            sc[kt] = mfma16<F16>(fk[0], fq[P - 1][ks], sc[kt]);
+          }
+          sc[kt] = mfma16<F16>(fk[0], fq[0][ks], sc[kt]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (k0 + kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
+          bm = fmaxf(bm, sc[kt][r]);
+        }
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mnew = fmaxf(m, bm);        // every block holds at least one valid key: finite
+      const float alpha = expf(m - mnew);     // first block: exp(-inf) = 0
+      float bs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KBT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = expf(sc[kt][r] - mnew);
+          sc[kt][r] = pv;
+          bs += pv;
+        }
+      bs += __shfl_xor(bs, 16, 64);
+      bs += __shfl_xor(bs, 32, 64);
+      l = l * alpha + bs;
+      m = mnew;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) oacc[dt] *= alpha;
+      // O^T += V^T P^T over the block's key-tile pairs
+#pragma unroll
+      for (int u = 0; u < KBT / 2; ++u) {
+        op16x8 fp[P];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float pv = jj < 4 ? sc[2 * u][jj] : sc[2 * u + 1][jj - 4];
+          op16_t hi, lo;
+          dsn_split(pv, hi, lo, F16);
+          fp[0][jj] = hi;
+          if (P == 2) fp[P - 1][jj] = lo;
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          op16x8 fv[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const op16_t* base = vlds + (long)p * KB * DH + dt * 16 + 4 * tp;
+            const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base + ((2 * u) * 16 + 4 * g + tq) * DH));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base + ((2 * u + 1) * 16 + 4 * g + tq) * DH));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              fv[p][e] = (unsigned short)lo4[e];
+              fv[p][4 + e] = (unsigned short)hi4[e];
+            }
+          }
+          if (P == 2) {
+            oacc[dt] = mfma16<F16>(fv[P - 1], fp[0], oacc[dt]);
+            oacc[dt] = mfma16<F16>(fv[0], fp[P - 1], oacc[dt]);
+          }
+          oacc[dt] = mfma16<F16>(fv[0], fp[0], oacc[dt]);
+        }
+      }
+    }
+    const int qi = qt * 16 + r16;
+    if (qi < S) {
+      const float inv = 1.f / l;
+      const long obase = ((long)b * S + qi) * D + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        op16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          op16_t a, c;
+          dsn_split(oacc[dt][r] * inv, a, c, F16);
+          hi[r] = a;
+          lo[r] = c;
+        }
+        *reinterpret_cast<op16x4*>(out + obase + dt * 16) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(out + out_ps + obase + dt * 16) = lo;
+      }
+    }
+  }
+}
+
 template <int P, int F16, int DH>
 void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S, int H, hipStream_t st) {
   const int nkt = (S + 15) / 16;
+  if (nkt > 16) {  // more than 256 keys: blocked keys + online softmax
+    const size_t sml = (size_t)P * 128 * DH * sizeof(op16_t);
+    static bool attr_l = false;
+    if (!attr_l) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<P, F16, DH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_l = true;
+    }
+    hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, nkt), dim3(64), sml, st, qkv, ps, out, out_ps, S,
+                       H);
+    return;
+  }
   const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);
   if (nkt <= 4) {
     hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out, out_ps,

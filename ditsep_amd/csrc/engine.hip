@@ -658,7 +658,6 @@ struct dsn_ctx {
     const int n = cfg.n_src, Dl = cfg.latent_dim, D = cfg.dit_embed_dim, H = cfg.dit_heads;
     const int io = n * Dl, din = io + Dl, S = T + 1;
     const long Mt = (long)B * T, M = (long)B * S;
-    if (S > 256) fail(DSN_EINVAL, "DiT attention kernel supports at most 255 latent frames (got T=%d)", T);
     op16_t* Up = wsbuf<op16_t>("dit_Up", Mt * din * P);
     float* X = wsbuf<float>("dit_X", M * D);
     op16_t* Ap = wsbuf<op16_t>("dit_Ap", M * D * P);

@@ -280,10 +280,12 @@ def test_graph_replay_matches_eager():
     eng.close()
 
 
-@pytest.mark.parametrize("T,prec,tol", [(100, X3, 1e-4), (235, FP16, 4e-3), (17, FP16X3, 1e-5)])
+@pytest.mark.parametrize("T,prec,tol", [(100, X3, 1e-4), (235, FP16, 4e-3), (17, FP16X3, 1e-5),
+                                        (300, X3, 1e-4), (470, FP16, 4e-3)])
 def test_dit_long_sequences(T, prec, tol):
     """Latent sequences beyond one 64-key block (the 16-key-tile attention variant); T=235 is the
-    30 s long-form shape of BASELINE config 5."""
+    30 s long-form shape of BASELINE config 5; T > 255 takes the blocked-key online-softmax kernel
+    (301 tokens = 2 full key blocks + a ragged one; 471 = 60 s at 16 kHz)."""
     cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
     sd = odit.random_dit_weights(cfg, 13)
     g = torch.Generator().manual_seed(14)
@@ -380,6 +382,26 @@ def test_ncsnpp_tiny_vs_golden(golden, tag, prec, tol):
     eng = make_engine(ncfg=cfg, nsd=sd, precision=prec)
     out = eng.score(torch.from_numpy(g["xt"]), torch.from_numpy(g["t"]), torch.from_numpy(g["mix"]))
     assert rel_l2(out, torch.from_numpy(g["out"])) < tol
+    eng.close()
+
+
+@pytest.mark.parametrize("T,prec,tol", [(72, X3, 2e-4), (236, FP16, 5e-3)])
+def test_ncsnpp_long_form_attention(T, prec, tol):
+    """NCSN++ attention over more than 256 positions (16 x T/4 at the attention resolution): T=72 -> 288,
+    T=236 -> 944 (the 30 s long-form shape of BASELINE config 5, W padded 235 -> 236)."""
+    from oracle import ncsnpp as oncs
+
+    cfg = oncs.NCSNppConfig(nf=32)
+    sd = oncs.random_ncsnpp_weights(cfg, 41)
+    g = torch.Generator().manual_seed(42)
+    Tin = T - 1 if T == 236 else T              # 235 frames: the wrapper pads W to a multiple of 4
+    xt = 2.0 * torch.randn((1, 2, 64, Tin), generator=g)
+    mix = torch.randn((1, 1, 64, Tin), generator=g)
+    t = torch.tensor([0.6])
+    ref = oncs.NCSNppScore(sd, cfg)(xt, t, mix)
+    eng = make_engine(ncfg=cfg, nsd=sd, precision=prec)
+    out = eng.score(xt, t, mix)
+    assert out.shape == ref.shape and rel_l2(out, ref) < tol
     eng.close()
 
 
