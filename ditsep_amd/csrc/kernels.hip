@@ -178,7 +178,9 @@ __global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ x
 // Residual-stream update fused with the next LayerNorm: x[row] += bias + sum of the split-K
 // partial slabs of the preceding GEMM (written back when any were added), then LayerNorm
 // (or a plain copy) to operand planes.  One wave per row, the row lives in registers.
-template <int MAXV>
+// NS = number of slabs at compile time: every load of a row (x, bias, all slabs) is issued before the first add,
+// one memory round trip instead of one per slab.
+template <int MAXV, int NS>
 __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restrict__ slabs, int nslab,
                                      long slab_stride, const float* __restrict__ bias,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -196,9 +198,13 @@ __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restr
       const int i = lane + k * 64;
       if (i < nv) {
         f32x4 a = reinterpret_cast<const f32x4*>(x + rbase)[i];
-        if (nslab > 0) {
+        if (NS > 0) {
+          f32x4 part[NS > 0 ? NS : 1];
+#pragma unroll
+          for (int z = 0; z < NS; ++z) part[z] = reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
           if (bias) a += reinterpret_cast<const f32x4*>(bias)[i];
-          for (int z = 0; z < nslab; ++z) a += reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
+#pragma unroll
+          for (int z = 0; z < NS; ++z) a += part[z];
           reinterpret_cast<f32x4*>(x + rbase)[i] = a;
         }
         v[k] = a;
@@ -521,12 +527,28 @@ void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, c
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
                           float eps, int do_norm, hipStream_t st) {
-  if (D <= 1024)
-    hipLaunchKernelGGL(residual_norm_kernel<4>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
-                       slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm);
-  else
-    hipLaunchKernelGGL(residual_norm_kernel<16>, dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab,
-                       slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm);
+#define RN_LAUNCH(MV, NS_)                                                                                       \
+  hipLaunchKernelGGL((residual_norm_kernel<MV, NS_>), dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab, \
+                     slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm)
+#define RN_SWITCH(MV)                                                                      \
+  switch (nslab) {                                                                         \
+    case 0: RN_LAUNCH(MV, 0); break;                                                       \
+    case 1: RN_LAUNCH(MV, 1); break;                                                       \
+    case 2: RN_LAUNCH(MV, 2); break;                                                       \
+    case 3: RN_LAUNCH(MV, 3); break;                                                       \
+    case 4: RN_LAUNCH(MV, 4); break;                                                       \
+    case 5: RN_LAUNCH(MV, 5); break;                                                       \
+    case 6: RN_LAUNCH(MV, 6); break;                                                       \
+    case 7: RN_LAUNCH(MV, 7); break;                                                       \
+    default: RN_LAUNCH(MV, 8); break;  /* pick_ksplit caps the split at 8 */               \
+  }
+  if (D <= 1024) {
+    RN_SWITCH(4)
+  } else {
+    RN_SWITCH(16)
+  }
+#undef RN_SWITCH
+#undef RN_LAUNCH
 }
 void launch_timestep_features(const float* t, const float* w, int B, int half, op16_t* out, long ps, int planes,
                               hipStream_t st) {
