@@ -757,3 +757,22 @@ def test_fused_residual_unit_full_size_deterministic_and_tight(monkeypatch):
     ref = ovae.decode_sources(vsd, vcfg, est, None, "decoder.")
     assert rel_l2(runs[0], ref) < 1e-3
     eng.close()
+
+
+def test_full_size_step_bit_reproducible():
+    """Full-size DiT + decoder, graphs on: the same inputs give bit-identical waveforms run after run (the DiT path
+    has no atomics; any difference is an intra-kernel race -- scripts/soak_determinism.py is the long version)."""
+    from ditsep_amd import synthetic
+    dcfg, vcfg = odit.DiTConfig(), ovae.OobleckConfig()
+    dsd = synthetic.random_dit_weights(dcfg, 1, out_gain=0.002, skip_gain=0.02)
+    vsd = {k: v for k, v in synthetic.vae_weights(vcfg, 2, dec_in_gain=0.08).items() if k.startswith("decoder.")}
+    eng = make_engine(dcfg, dsd, vcfg, vsd, precision=FP16)
+    eng.enable_graphs(True)
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn((16, 1, 64, 32), generator=g)
+    outs = []
+    for _ in range(4):                      # eager, capture, 2 replays
+        x, _ = eng.pc_sample(y, None, N=6, corrector_steps=1, snr=0.5, seed=11)
+        outs.append(eng.decode(x, 64000).cpu())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    eng.close()
