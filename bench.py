@@ -213,6 +213,14 @@ def main():
                 "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
                 "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
                 "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
+    if prof["hbm_launches"]:
+        # second-largest kernel class: the fused ResidualUnit of the 128-channel decoder layers, HBM bound
+        gbs = prof["hbm_bytes"] / (prof["hbm_ms"] * 1e-3) / 1e9
+        roofline["secondary"] = {"kernel": "ru_fused2_kernel (fused Oobleck ResidualUnit, 128 ch)", "bound": "hbm",
+                                 "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(gbs / 8000.0, 4), "launches_per_step": prof["hbm_launches"],
+                                 "avg_launch_us": round(1e3 * prof["hbm_ms"] / prof["hbm_launches"], 1),
+                                 "algorithmic_gb_per_step": round(prof["hbm_bytes"] / 1e9, 2)}
 
     out = {
         "metric": "separated utterances/sec @ N=30, 2-spk 4 s mixtures",

@@ -92,6 +92,7 @@ struct Graph {
 struct ProfRec {
   hipEvent_t a, b;
   double flops;
+  double hbm_bytes = 0;  // > 0: an HBM-bound launch (fused ResidualUnit), algorithmic bytes
 };
 
 }  // namespace
@@ -103,6 +104,8 @@ struct dsn_ctx {
   int PL = 2;  // DSN_PL(P, fp16 flag) as the kernels take it
   bool finalized = false;
   bool use_graphs = false;
+  double hbm_ms = 0, hbm_bytes = 0;  // HBM-bound launches of the last profiled region (dsn_profile_hbm)
+  int64_t hbm_launches = 0;
   std::map<std::string, DevTensor> raw;
   std::vector<void*> allocs;
   std::map<std::string, std::pair<void*, size_t>> ws;
@@ -613,6 +616,8 @@ struct dsn_ctx {
       HIPCHK(hipEventCreate(&pr.a));
       HIPCHK(hipEventCreate(&pr.b));
       pr.flops = 2.0 * (double)S * (double)L * 128.0 * 128.0 * 8.0;
+      // algorithmic HBM bytes: planes in, fp32 residual in, fp32 out (when kept), planes out
+      pr.hbm_bytes = (double)S * (double)L * 128.0 * (2.0 * P + 4.0 + (out_f32 ? 4.0 : 0.0) + 2.0 * P);
       HIPCHK(hipEventRecord(pr.a, st));
     }
     hipError_t e = ru_fused_launch(d, PL, st);
@@ -1567,11 +1572,18 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
   return guarded(ctx, [&] {
     HIPCHK(hipDeviceSynchronize());
     double ms = 0, fl = 0;
+    ctx->hbm_ms = ctx->hbm_bytes = 0;
+    ctx->hbm_launches = 0;
     for (auto& r : ctx->prof) {
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
       ms += t;
       fl += r.flops;
+      if (r.hbm_bytes > 0) {
+        ctx->hbm_ms += t;
+        ctx->hbm_bytes += r.hbm_bytes;
+        ++ctx->hbm_launches;
+      }
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
     }
@@ -1581,6 +1593,14 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
     ctx->prof.clear();
     ctx->profiling = false;
   });
+}
+
+int dsn_profile_hbm(dsn_ctx* ctx, double* ms, double* bytes, int64_t* launches) {
+  if (!ctx) return DSN_EINVAL;
+  if (ms) *ms = ctx->hbm_ms;
+  if (bytes) *bytes = ctx->hbm_bytes;
+  if (launches) *launches = ctx->hbm_launches;
+  return DSN_OK;
 }
 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N, int taps,

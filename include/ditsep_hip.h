@@ -176,6 +176,10 @@ int64_t dsn_workspace_bytes(const dsn_ctx* ctx);
  * 3x split-bf16 passes not counted) and the launch count. */
 int dsn_profile_begin(dsn_ctx* ctx);
 int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches);
+/* of the region closed by the last dsn_profile_end: the HBM-bound fused ResidualUnit launches alone (they are
+ * also part of the totals above) -- summed kernel time, ALGORITHMIC bytes (operand planes in, fp32 residual in,
+ * fp32 and planes out), launch count */
+int dsn_profile_hbm(dsn_ctx* ctx, double* ms, double* bytes, int64_t* launches);
 
 /* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
  * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */
