@@ -342,6 +342,78 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const op16_t* __restrict
   }
 }
 
+// Same convolution, each input row read ONCE (C % 32 == 0, at most 8 taps): 4 lanes per row take interleaved
+// 8-channel chunks (64 contiguous bytes per row per load), form the row's KT per-tap partial dot products against
+// weights broadcast from LDS, reduce over the 4 lanes, and a second pass adds the KT shifted partials per output.
+// The first version re-read every staged row KT times from LDS (LDS bound, 22 % of the HBM roofline).
+template <int KT>
+__global__ __launch_bounds__(256) void conv_out1_rows_kernel(const op16_t* __restrict__ a, long ps, int planes,
+                                                             const float* __restrict__ w, float* __restrict__ out,
+                                                             int L, int C, int apply_tanh) {
+  constexpr int TILE = 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NJ = C / 32;
+  f32x4* wl4 = reinterpret_cast<f32x4*>(smem);  // [KT][NJ][2][4 lanes] float4
+  float* part = smem + KT * C;                  // [TILE + KT - 1][8]
+  const int blocks_per_seq = (L + TILE - 1) / TILE;
+  const int s = blockIdx.x / blocks_per_seq;
+  const int l0 = (blockIdx.x - s * blocks_per_seq) * TILE;
+  const int pad = (KT - 1) / 2;
+  for (int i = threadIdx.x; i < KT * C; i += blockDim.x) {
+    const int t = i / C, c = i - t * C;
+    const int chunk = c >> 3, k = c & 7;
+    const int j = chunk >> 2, q = chunk & 3;
+    smem[((((t * NJ + j) * 2 + (k >> 2)) * 4 + q) << 2) + (k & 3)] = w[i];
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const bool f16 = PL_F16(planes), two = PL_COUNT(planes) == 2;
+  for (int r = threadIdx.x >> 2; r < TILE + KT - 1; r += 64) {
+    const int l = l0 - pad + r;
+    float acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[t] = 0.f;
+    if (l >= 0 && l < L) {
+      const op16_t* row = a + ((long)s * L + l) * C;
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = (j * 4 + q) * 8;
+        const op16x8 hi = *reinterpret_cast<const op16x8*>(row + ch);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = from_op16(hi[k], f16);
+        if (two) {
+          const op16x8 lo = *reinterpret_cast<const op16x8*>(row + ps + ch);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += from_op16(lo[k], f16);
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const f32x4 wa = wl4[((t * NJ + j) * 2 + 0) * 4 + q], wb = wl4[((t * NJ + j) * 2 + 1) * 4 + q];
+          acc[t] += (v[0] * wa[0] + v[1] * wa[1]) + (v[2] * wa[2] + v[3] * wa[3]) + (v[4] * wb[0] + v[5] * wb[1]) +
+                    (v[6] * wb[2] + v[7] * wb[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      float x = acc[t];
+      x += __shfl_xor(x, 1, 64);
+      x += __shfl_xor(x, 2, 64);
+      if (q == 0) part[r * 8 + t] = x;
+    }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < TILE; p += blockDim.x) {
+    const int l = l0 + p;
+    if (l < L) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) v += part[(p + t) * 8 + t];
+      out[(long)s * L + l] = apply_tanh ? tanhf(v) : v;
+    }
+  }
+}
+
 __global__ void conv_in1_kernel(const float* __restrict__ wav, const float* __restrict__ w,
                                 const float* __restrict__ bias, int L, int Cout, int ktaps,
                                 float* __restrict__ of, op16_t* __restrict__ op, long ps, int planes, int act,
@@ -560,6 +632,12 @@ void launch_rope_tables(float* ct, float* stb, int S, int rot, hipStream_t st) {
 }
 void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, float* out, int S, int L, int C,
                       int ktaps, int apply_tanh, hipStream_t st) {
+  if (ktaps == 7 && C % 32 == 0 && C <= 1024) {
+    const size_t smr = ((size_t)7 * C + (size_t)(256 + 6) * 8) * sizeof(float);
+    hipLaunchKernelGGL(conv_out1_rows_kernel<7>, dim3(S * ((L + 255) / 256)), dim3(256), smr, st, a, ps, planes, w,
+                       out, L, C, apply_tanh);
+    return;
+  }
   const size_t sm = ((size_t)(64 + ktaps - 1) * (C + 4) + (size_t)ktaps * C + 256) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
