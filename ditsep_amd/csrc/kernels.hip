@@ -439,6 +439,59 @@ __global__ void conv_in1_kernel(const float* __restrict__ wav, const float* __re
   }
 }
 
+// Cin == 1 convolution, 4 output channels per thread (Cout % 4 == 0, ktaps <= 8): the thread's 4 x ktaps weights
+// and biases stay in registers, outputs leave as 16-byte fp32 / 8-byte plane stores (the scalar version above wrote
+// 2-byte plane elements)
+__global__ void conv_in1_vec_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                    const float* __restrict__ bias, int L, int Cout, int ktaps,
+                                    float* __restrict__ of, op16_t* __restrict__ op, long ps, int planes, int act,
+                                    const float* __restrict__ aa, const float* __restrict__ ab, long rows) {
+  const int cq = Cout >> 2;
+  const int c4 = (threadIdx.x % cq) * 4;  // blockDim.x % cq == 0: a thread keeps its channels across rows
+  const int pad = (ktaps - 1) / 2;
+  float wr[4][8];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) wr[r][t] = t < ktaps ? w[(c4 + r) * ktaps + t] : 0.f;
+    if (bias) bv[r] = bias[c4 + r];
+  }
+  const int rpb = blockDim.x / cq;
+  for (long row = blockIdx.x * (long)rpb + threadIdx.x / cq; row < rows; row += (long)gridDim.x * rpb) {
+    const int l = (int)(row % L);
+    const long s = row / L;
+    float x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int li = l + t - pad;
+      x[t] = (t < ktaps && li >= 0 && li < L) ? wav[s * L + li] : 0.f;
+    }
+    f32x4 acc = bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[r] += wr[r][t] * x[t];
+    const long o = row * Cout + c4;
+    if (of) *reinterpret_cast<f32x4*>(of + o) = acc;
+    if (op) {
+      op16x4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[r];
+        if (act == DSN_ACT_ELU) v = dsn_elu(v);
+        else if (act == DSN_ACT_SNAKE) v = dsn_snake(v, aa[c4 + r], ab[c4 + r]);
+        op16_t h, lw;
+        dsn_split(v, h, lw, PL_F16(planes));
+        hi[r] = h;
+        lo[r] = lw;
+      }
+      *reinterpret_cast<op16x4*>(op + o) = hi;
+      if (PL_COUNT(planes) == 2) *reinterpret_cast<op16x4*>(op + ps + o) = lo;
+    }
+  }
+}
+
 __global__ void vae_sample_kernel(const float* __restrict__ enc, const float* __restrict__ noise,
                                   float* __restrict__ y, int D, int T, long total) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -652,6 +705,12 @@ void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, floa
 void launch_conv_in1(const float* wav, const float* w, const float* bias, int S, int L, int Cout, int ktaps,
                      float* of, op16_t* op, long ps, int planes, int act, const float* aa, const float* ab,
                      hipStream_t st) {
+  if (Cout % 4 == 0 && TPB % (Cout / 4) == 0 && ktaps <= 8) {
+    const long rows = (long)S * L;
+    hipLaunchKernelGGL(conv_in1_vec_kernel, dim3(grid_for(rows * (Cout / 4))), dim3(TPB), 0, st, wav, w, bias, L, Cout,
+                       ktaps, of, op, ps, planes, act, aa, ab, rows);
+    return;
+  }
   const long total = (long)S * L * Cout;
   hipLaunchKernelGGL(conv_in1_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, wav, w, bias, L, Cout, ktaps, of, op,
                      ps, planes, act, aa, ab, total);
