@@ -231,9 +231,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "C2 Libri2Mix-shape: 2-spk 16 kHz 4 s mixtures, N=30 PC sampler "
                                "(reverse_diffusion + ald, 1 corrector step, 60 NFE) + Oobleck decode, "
-                               f"batch={B} per GPU",
-                   "score_net": score_desc,
-                   "vae": "Oobleck decoder 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
+                               f"batch={B} per GPU; score function: {score_desc}; "
+                               "decoder: Oobleck 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
                    "global_batch": world * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
                    "pipelined_decode": pipelined,
                    "parallelism": f"dp{world}: batch sharded, one RCCL gather of waveforms per step"},
