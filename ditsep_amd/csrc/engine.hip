@@ -698,8 +698,28 @@ struct dsn_ctx {
     // (+ bias + residual) is fused into the LayerNorm that follows.
     static const bool no_panel = getenv("DSN_NO_PANEL") != nullptr;
     const bool use_panel = !no_panel && (D % 64 == 0);
+    // Short row panels (<= 144 rows, 9 row sub-tiles) for the three narrower GEMMs in the single-plane modes:
+    // at M = 2112 -> 16 panels of 132 rows; out-proj 16 x 8 x split-K 2 and FF-out 16 x 4 x split-K 4 are exactly
+    // 256 workgroups, QKV 16 x 12 = 192 (sweep: profiles/r01_gemm_sweep_dit_panel132.log).  Smaller problems
+    // keep the tile kernel + pick_ksplit.
+    static const bool no_short = getenv("DSN_NO_SHORT_PANEL") != nullptr;
+    const bool short_panel = use_panel && !no_short && P == 1 && M >= 1024;
+    int rows132 = 0;
+    if (short_panel) {
+      int best_np = 0;
+      long best_cost = 0;
+      for (int np = cdiv(M, 144); np <= cdiv(M, 144) + 2; ++np) {
+        const int rows = (cdiv(M, np) + 7) / 8 * 8;
+        const long cost = (long)cdiv((long)np * 8 * 2, 256) * rows;  // rounds of the out-proj grid x panel height
+        if (!best_np || cost < best_cost) {
+          best_np = np;
+          best_cost = cost;
+          rows132 = rows;
+        }
+      }
+    }
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
-    const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : 0;
+    const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : (short_panel ? 256 : 0);
     float* slabs = nullptr;
     int pend_n = 0;
     const float* pend_bias = nullptr;
@@ -720,14 +740,15 @@ struct dsn_ctx {
         d.m_fast = 1;
         if (qkv_panel) {
           const int np = cdiv(M, 272);
-          d.panel_rows = (cdiv(M, np) + 7) / 8 * 8;
+          d.panel_rows = short_panel ? rows132 : (cdiv(M, np) + 7) / 8 * 8;
         }
         run(d, st, qkv_panel);
       }
       launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
-        d.ksplit = pick_ksplit(d);
+        d.ksplit = short_panel ? 2 : pick_ksplit(d);
+        if (short_panel) d.panel_rows = rows132;
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -737,7 +758,7 @@ struct dsn_ctx {
           d.resid = X;
           d.out_f32 = X;
         }
-        run(d, st);
+        run(d, st, short_panel ? 128 : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
       }
@@ -762,7 +783,8 @@ struct dsn_ctx {
       }
       {
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
-        d.ksplit = pick_ksplit(d);
+        d.ksplit = short_panel ? 4 : pick_ksplit(d);
+        if (short_panel) d.panel_rows = rows132;
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -774,7 +796,7 @@ struct dsn_ctx {
           d.out_f32 = X;
           pend_bias = nullptr;
         }
-        run(d, st);
+        run(d, st, short_panel ? 256 : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
       }
     }
