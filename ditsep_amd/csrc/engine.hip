@@ -698,26 +698,18 @@ struct dsn_ctx {
     // (+ bias + residual) is fused into the LayerNorm that follows.
     static const bool no_panel = getenv("DSN_NO_PANEL") != nullptr;
     const bool use_panel = !no_panel && (D % 64 == 0);
-    // Short row panels (<= 144 rows, 9 row sub-tiles) for the three narrower GEMMs in the single-plane modes:
-    // at M = 2112 -> 16 panels of 132 rows; out-proj 16 x 8 x split-K 2 and FF-out 16 x 4 x split-K 4 are exactly
-    // 256 workgroups, QKV 16 x 12 = 192 (sweep: profiles/r01_gemm_sweep_dit_panel132.log).  Smaller problems
-    // keep the tile kernel + pick_ksplit.
+    // Short row panels for the three narrower GEMMs in the single-plane modes, sized so that panels x column tiles
+    // x split-K is one balanced round of 256 workgroups: at M = 2112 out-proj 16 x 8 x split-K 2 and FF-out
+    // 16 x 4 x split-K 4 (132-row panels, 9 sub-tiles) = 256, QKV 21 x 12 (104-row panels, 7 sub-tiles) = 252
+    // (sweep: profiles/r01_gemm_sweep_dit_panel132.log).  Smaller problems keep the tile kernel + pick_ksplit.
     static const bool no_short = getenv("DSN_NO_SHORT_PANEL") != nullptr;
-    const bool short_panel = use_panel && !no_short && P == 1 && M >= 1024;
-    int rows132 = 0;
-    if (short_panel) {
-      int best_np = 0;
-      long best_cost = 0;
-      for (int np = cdiv(M, 144); np <= cdiv(M, 144) + 2; ++np) {
-        const int rows = (cdiv(M, np) + 7) / 8 * 8;
-        const long cost = (long)cdiv((long)np * 8 * 2, 256) * rows;  // rounds of the out-proj grid x panel height
-        if (!best_np || cost < best_cost) {
-          best_np = np;
-          best_cost = cost;
-          rows132 = rows;
-        }
-      }
-    }
+    const bool short_panel = use_panel && !no_short && P == 1 && M >= 1024;  // split modes: measured, no gain
+    // panel height for a GEMM with `wg_per_panel` = column tiles x split-K workgroups per row panel: as many
+    // panels as fit one round of 256 CUs, but never taller than the kernel's 272 rows
+    auto panel_rows_for = [&](int wg_per_panel) {
+      const int np = std::max(256 / std::max(1, wg_per_panel), cdiv(M, 272));
+      return (cdiv(M, np) + 7) / 8 * 8;
+    };
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
     const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : (short_panel ? 256 : 0);
     float* slabs = nullptr;
@@ -740,7 +732,7 @@ struct dsn_ctx {
         d.m_fast = 1;
         if (qkv_panel) {
           const int np = cdiv(M, 272);
-          d.panel_rows = short_panel ? rows132 : (cdiv(M, np) + 7) / 8 * 8;
+          d.panel_rows = short_panel ? panel_rows_for(cdiv(3 * D, qkv_panel)) : (cdiv(M, np) + 7) / 8 * 8;
         }
         run(d, st, qkv_panel);
       }
@@ -748,7 +740,7 @@ struct dsn_ctx {
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         d.ksplit = short_panel ? 2 : pick_ksplit(d);
-        if (short_panel) d.panel_rows = rows132;
+        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, 128) * 2);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -784,7 +776,7 @@ struct dsn_ctx {
       {
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
         d.ksplit = short_panel ? 4 : pick_ksplit(d);
-        if (short_panel) d.panel_rows = rows132;
+        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, 256) * 4);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;

@@ -581,15 +581,15 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 // masked.  Staging / ring / swizzle as in igemm2_kernel (BK = 32); row groups are dealt round-robin
 // to the waves, so the per-wave glds count (and its vmcnt) differs by one between waves.
 // ============================================================================
-template <int P, int F16, int WN_, int NST, int TBK, int MTW = 5>
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17>
 __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const GemmDesc d,
                                                                          const op16_t* __restrict__ zero_page) {
-  // 4 wave rows x WN_ wave columns; wave row 0 owns MTW row sub-tiles, rows 1..3 own MTW-1 each:
-  // MTW = 5: 17 sub-tiles = 272 rows (8 panels of 264 for M = 2112); MTW = 3: 9 sub-tiles = 144 rows (16 panels of
-  // 132).  Every wave owns 4 column sub-tiles (64 columns).
+  // 4 wave rows x WN_ wave columns; the MT row sub-tiles of a panel are dealt MT/4 (+1 for the first MT%4 wave rows):
+  // MT = 17: 5/4/4/4 = 272 rows (8 panels of 264 for M = 2112); MT = 9: 3/2/2/2 = 144 rows (16 panels of 132);
+  // MT = 7: 2/2/2/1 = 112 rows.  Every wave owns 4 column sub-tiles (64 columns).
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows (TBN) | pad][TBK]
   constexpr int NWAVES = 4 * WN_;
-  constexpr int MT = 4 * MTW - 3;
+  constexpr int MTW = (MT + 3) / 4;
   constexpr int TBN = WN_ * 64;
   constexpr int AROWS = MT * 16;
   constexpr int ROWS = AROWS + TBN;
@@ -606,8 +606,9 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
-  const int my_mt = wave_m == 0 ? MTW : MTW - 1;
-  const int my_row0 = wave_m == 0 ? 0 : 16 * MTW + (wave_m - 1) * 16 * (MTW - 1);
+  constexpr int MBASE = MT / 4, MREM = MT % 4;
+  const int my_mt = MBASE + (wave_m < MREM ? 1 : 0);
+  const int my_row0 = 16 * (wave_m * MBASE + min(wave_m, MREM));
   const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -825,21 +826,20 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
 }
 
 // Row-panel launcher: d.panel_rows rows per workgroup (<= 272), bn in {128, 256}.
-template <int P, int F16, int WN_, int NST, int TBK, int MTW = 5>
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17>
 static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   constexpr int TBN = WN_ * 64;
-  constexpr int MT = 4 * MTW - 3;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MTW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t);
-  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MTW>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
+  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
                      zp);
   return hipGetLastError();
 }
@@ -857,13 +857,16 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
 #define PCFG(P_, W_, NS_, BK_)                                                                   \
   if (planes == P_ && bn == W_ * 64)                                                             \
     return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_>(d, zp, stream);
-  if (d.panel_rows <= 9 * 16) {  // short panels (e.g. 16 x 132 rows): 9 row sub-tiles, deeper ring fits
-#define PCFG9(P_, W_, NS_, BK_)                                                  \
-  if (planes == P_ && bn == W_ * 64)                                             \
-    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, 3>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_, 3>(d, zp, stream);
-    PCFG9(1, 4, 3, 64) PCFG9(1, 2, 3, 64) PCFG9(2, 4, 2, 32) PCFG9(2, 2, 2, 32)
-#undef PCFG9
+#define PCFGS(MT_, P_, W_, NS_, BK_)                                                  \
+  if (planes == P_ && bn == W_ * 64)                                                  \
+    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, MT_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_, MT_>(d, zp, stream);
+  if (d.panel_rows <= 7 * 16) {  // 112-row panels (single-plane modes)
+    PCFGS(7, 1, 4, 3, 64)
   }
+  if (d.panel_rows <= 9 * 16) {  // short panels (e.g. 16 x 132 rows): 9 row sub-tiles, a 3-stage ring fits
+    PCFGS(9, 1, 4, 3, 64) PCFGS(9, 1, 2, 3, 64) PCFGS(9, 2, 4, 2, 32) PCFGS(9, 2, 2, 2, 32)
+  }
+#undef PCFGS
   PCFG(1, 4, 2, 64) PCFG(1, 2, 2, 64) PCFG(2, 4, 2, 32) PCFG(2, 2, 2, 32)
 #undef PCFG
   return hipErrorInvalidValue;
