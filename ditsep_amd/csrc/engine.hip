@@ -739,8 +739,11 @@ struct dsn_ctx {
       launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
       {
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
-        d.ksplit = short_panel ? 2 : pick_ksplit(d);
-        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, 128) * 2);
+        static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
+        int obn = 128, oks = 2;
+        if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
+        d.ksplit = short_panel ? oks : pick_ksplit(d);
+        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -750,7 +753,7 @@ struct dsn_ctx {
           d.resid = X;
           d.out_f32 = X;
         }
-        run(d, st, short_panel ? 128 : 0);
+        run(d, st, short_panel ? obn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
       }
@@ -775,8 +778,11 @@ struct dsn_ctx {
       }
       {
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
-        d.ksplit = short_panel ? 4 : pick_ksplit(d);
-        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, 256) * 4);
+        static const char* fcfg = getenv("DSN_FF2_CFG");
+        int fbn = 256, fks = 4;
+        if (fcfg) sscanf(fcfg, "%d,%d", &fbn, &fks);
+        d.ksplit = short_panel ? fks : pick_ksplit(d);
+        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -788,7 +794,7 @@ struct dsn_ctx {
           d.out_f32 = X;
           pend_bias = nullptr;
         }
-        run(d, st, short_panel ? 256 : 0);
+        run(d, st, short_panel ? fbn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
       }
     }
