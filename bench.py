@@ -209,7 +209,7 @@ def main():
         traffic = round((nfe * pm["score_call_hbm_bytes"] + pm["decode_hbm_bytes"]) / launches)
     roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
-                "kernel": "igemm2_kernel (implicit-GEMM MFMA, %s)" % args.precision, "launches_per_step": prof["gemm_launches"],
+                "kernel": "igemm_panel_kernel / igemm2_kernel (implicit-GEMM MFMA family, all launches, %s)" % args.precision, "launches_per_step": prof["gemm_launches"],
                 "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
                 "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
                 "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
