@@ -777,3 +777,24 @@ def test_full_size_step_bit_reproducible():
         outs.append(eng.decode(x, 64000).cpu())
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     eng.close()
+
+
+@pytest.mark.parametrize("B,T", [(32, 32), (40, 27)])
+def test_dit_balanced_panel_path_vs_oracle(B, T):
+    """M = B*(T+1) >= 1024 rows switches the single-plane modes to the balanced row-panel grids (QKV / out-proj
+    with split-K 2 / FF-in / FF-out with split-K 4); small model, so the panels are only 16-24 rows tall and
+    every masking path of the panel kernel is exercised."""
+    cfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    sd = odit.random_dit_weights(cfg, 51)
+    g = torch.Generator().manual_seed(52)
+    xt = 2.0 * torch.randn((B, 2, 64, T), generator=g)
+    mix = torch.randn((B, 1, 64, T), generator=g)
+    t = torch.rand((B,), generator=g) * 0.9 + 0.05
+    ref = odit.DiTScore(sd, cfg)(xt, t, mix)
+    eng = make_engine(cfg, sd, precision=FP16)
+    out = eng.score(xt, t, mix)
+    assert rel_l2(out, ref) < 4e-3
+    eng.close()
+    eng = make_engine(cfg, sd, precision=X3)          # split mode: tile kernels, the tight bound
+    assert rel_l2(eng.score(xt, t, mix), ref) < 1e-4
+    eng.close()
