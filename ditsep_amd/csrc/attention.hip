@@ -24,10 +24,12 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int P, int F16, int NKT, int DH>
-__global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __restrict__ qkv, long ps,
-                                                            op16_t* __restrict__ out, long out_ps, int S, int H) {
+__global__ __launch_bounds__(512) void attention_mfma_kernel(const op16_t* __restrict__ qkv, long ps,
+                                                             op16_t* __restrict__ out, long out_ps, int S, int H) {
+  // blockDim.x / 64 waves per workgroup: they stage V once and each take query tiles of the same (item, head)
   extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][nkt*16][DH]
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * DH;
   const long rs = 3L * D;  // token row stride
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   constexpr bool PREFETCH = (NKT <= 4 && DH == 64);
   op16x8 pq[P][KSD], pk[PREFETCH ? NKT : 1][P][KSD];
   if (PREFETCH) {
-    const int qrow0 = min((int)blockIdx.y * 16 + r16, S - 1);
+    const int qrow0 = min(((int)blockIdx.y * nwaves + wave) * 16 + r16, S - 1);
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
   // stage V (zero beyond S) -- DH/8 lanes x 16 B per token row
   constexpr int CPRV = DH / 8;
   const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int idx = lane; idx < vrows * CPRV; idx += 64) {
+  for (int idx = threadIdx.x; idx < vrows * CPRV; idx += blockDim.x) {
     const int row = idx / CPRV, c = idx % CPRV;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
 
   // one query tile per workgroup (blockIdx.y): short sequences are latency bound, so spread the query
   // tiles over more waves (V is staged redundantly, it is small)
-  for (int qt = blockIdx.y; qt < nkt; qt += gridDim.y) {
+  const int qt0 = blockIdx.y * nwaves + wave;
+  for (int qt = qt0; qt < nkt; qt += gridDim.y * nwaves) {
     // ---- scores^T = K Q^T -------------------------------------------------
     const int qrow = min(qt * 16 + r16, S - 1);
     op16x8 fq[P][KSD];
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const op16_t* __rest
     for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int ks = 0; ks < KSD; ++ks)
-        fq[p][ks] = (PREFETCH && qt == (int)blockIdx.y)
+        fq[p][ks] = (PREFETCH && qt == qt0)
                         ? pq[p][ks]
                         : *reinterpret_cast<const op16x8*>(qb + p * ps + qrow * rs + ks * 32 + g * 8);
     f32x4 sc[NKT];
@@ -374,8 +377,10 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out,
-                       out_ps, S, H);
+    // wide heads stage a large V block (DH * nkt * 32 B): share it between the query tiles' waves
+    const int W = DH >= 128 ? (nkt >= 8 ? 8 : (nkt >= 4 ? 4 : 1)) : 1;
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sm, st,
+                       qkv, ps, out, out_ps, S, H);
   }
 }
 
