@@ -701,9 +701,10 @@ struct dsn_ctx {
     // Short row panels for the three narrower GEMMs in the single-plane modes, sized so that panels x column tiles
     // x split-K is one balanced round of 256 workgroups: at M = 2112 out-proj 16 x 8 x split-K 2 and FF-out
     // 16 x 4 x split-K 4 (132-row panels, 9 sub-tiles) = 256, QKV 21 x 12 (104-row panels, 7 sub-tiles) = 252
-    // (sweep: profiles/r01_gemm_sweep_dit_panel132.log).  Smaller problems keep the tile kernel + pick_ksplit.
+    // (sweep: profiles/r01_gemm_sweep_dit_panel132.log).
     static const bool no_short = getenv("DSN_NO_SHORT_PANEL") != nullptr;
-    const bool short_panel = use_panel && !no_short && P == 1 && M >= 1024;  // split modes: measured, no gain
+    // (also for small batches: many short panels keep every CU streaming weights -- B = 8: 197 -> 145 ms per step)
+    const bool short_panel = use_panel && !no_short && P == 1;  // split modes: measured, no gain
     // panel height for a GEMM with `wg_per_panel` = column tiles x split-K workgroups per row panel: as many
     // panels as fit one round of 256 CUs, but never taller than the kernel's 272 rows
     auto panel_rows_for = [&](int wg_per_panel) {
@@ -772,7 +773,7 @@ struct dsn_ctx {
         d.m_fast = 1;
         if (use_panel) {
           const int np = cdiv(M, 272);
-          d.panel_rows = (cdiv(M, np) + 7) / 8 * 8;
+          d.panel_rows = short_panel ? panel_rows_for(cdiv(4 * D * 2, 256)) : (cdiv(M, np) + 7) / 8 * 8;
         }
         run(d, st, use_panel ? 256 : 0);
       }
