@@ -706,10 +706,13 @@ struct dsn_ctx {
     // (also for small batches: many short panels keep every CU streaming weights -- B = 8: 197 -> 145 ms per step)
     const bool short_panel = use_panel && !no_short && P == 1;  // split modes: measured, no gain
     // panel height for a GEMM with `wg_per_panel` = column tiles x split-K workgroups per row panel: as many
-    // panels as fit one round of 256 CUs, but never taller than the kernel's 272 rows
+    // panels as fill whole rounds of 256 CUs
     auto panel_rows_for = [&](int wg_per_panel) {
-      const int np = std::max(256 / std::max(1, wg_per_panel), cdiv(M, 272));
-      return (cdiv(M, np) + 7) / 8 * 8;
+      for (int rounds = 1;; ++rounds) {  // whole rounds of 256 workgroups, panels at most 272 rows tall
+        const int np = std::max(1, 256 * rounds / std::max(1, wg_per_panel));
+        const int rows = (cdiv(M, np) + 7) / 8 * 8;
+        if (rows <= 272) return rows;
+      }
     };
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
     const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : (short_panel ? 256 : 0);

@@ -866,6 +866,9 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
   if (d.panel_rows <= 9 * 16) {  // short panels (e.g. 16 x 132 rows): 9 row sub-tiles, a 3-stage ring fits
     PCFGS(9, 1, 4, 3, 64) PCFGS(9, 1, 2, 3, 64) PCFGS(9, 2, 4, 2, 32) PCFGS(9, 2, 2, 2, 32)
   }
+  if (d.panel_rows <= 13 * 16) {  // 13 sub-tiles (large batches: two rounds of 208-row panels)
+    PCFGS(13, 1, 4, 2, 64) PCFGS(13, 1, 2, 2, 64)
+  }
 #undef PCFGS
   PCFG(1, 4, 2, 64) PCFG(1, 2, 2, 64) PCFG(2, 4, 2, 32) PCFG(2, 2, 2, 32)
 #undef PCFG

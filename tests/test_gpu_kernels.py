@@ -74,7 +74,7 @@ def test_igemm_strided_conv(bare, stride):
 
 @pytest.mark.parametrize("prec", [X3, FP16])
 @pytest.mark.parametrize("M,rows,bn", [(2112, 264, 256), (2112, 264, 128), (66, 72, 256), (500, 256, 128), (1000, 200, 256),
-                                       (2112, 132, 256), (2112, 132, 128), (700, 144, 256), (100, 40, 128), (2112, 112, 256), (500, 104, 256)])
+                                       (2112, 132, 256), (2112, 132, 128), (700, 144, 256), (100, 40, 128), (2112, 112, 256), (500, 104, 256), (2112, 208, 256), (900, 176, 128)])
 def test_igemm_row_panel_kernel(bare, prec, M, rows, bn):
     """Row-panel GEMM variant (equal row panels <= 272 rows; last sub-tile partly masked)."""
     g = torch.Generator().manual_seed(5)
