@@ -356,11 +356,10 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
   const int nkt = (S + 15) / 16;
   if (nkt > 16) {  // more than 256 keys: blocked keys + online softmax
     const size_t sml = (size_t)P * 128 * DH * sizeof(op16_t);
-    static bool attr_l = false;
-    if (!attr_l) {
+    static std::atomic<unsigned long long> attr_l{0};
+    if (dsn_first_use_on_device(attr_l)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<P, F16, DH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_l = true;
     }
     hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, nkt), dim3(64), sml, st, qkv, ps, out, out_ps, S,
                        H);
@@ -371,11 +370,10 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
     hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out, out_ps,
                        S, H);
   } else {
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};
+    if (dsn_first_use_on_device(attr)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<P, F16, 16, DH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
     }
     // wide heads stage a large V block (DH * nkt * 32 B): share it between the query tiles' waves
     const int W = DH >= 128 ? (nkt >= 8 ? 8 : (nkt >= 4 ? 4 : 1)) : 1;

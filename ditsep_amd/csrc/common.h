@@ -75,3 +75,18 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time per-DEVICE setup from host launch code (function attributes, zero pages): several engine contexts on
+// different GPUs may live in one process, so "done once per process" is not enough.
+#include <atomic>
+inline int dsn_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev & 63;
+}
+inline bool dsn_first_use_on_device(std::atomic<unsigned long long>& mask) {
+  const unsigned long long bit = 1ull << dsn_current_device();
+  if (mask.load(std::memory_order_relaxed) & bit) return false;
+  mask.fetch_or(bit, std::memory_order_relaxed);
+  return true;
+}

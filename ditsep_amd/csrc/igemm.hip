@@ -729,23 +729,23 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
 }
 
 const op16_t* zero_page() {
-  static op16_t* zp = nullptr;
-  if (!zp) {
-    if (hipMalloc((void**)&zp, 4096) != hipSuccess) return nullptr;
-    (void)hipMemset(zp, 0, 4096);
+  static op16_t* zp[64] = {};
+  op16_t*& z = zp[dsn_current_device()];
+  if (!z) {
+    if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
+    (void)hipMemset(z, 0, 4096);
   }
-  return zp;
+  return z;
 }
 
 template <int P, int F16, int TBM, int TBN, int NST, int TBK>
 hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = cdiv(d.M, TBM);
   d.tiles_n = cdiv(d.N, TBN);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (TBM + TBN) * TBK * sizeof(op16_t);
@@ -831,11 +831,10 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
   constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t);

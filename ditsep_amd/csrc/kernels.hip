@@ -692,11 +692,10 @@ void launch_conv_out1(const op16_t* a, long ps, int planes, const float* w, floa
     return;
   }
   const size_t sm = ((size_t)(64 + ktaps - 1) * (C + 4) + (size_t)ktaps * C + 256) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  if (dsn_first_use_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out1_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const int blocks = S * ((L + 63) / 64);
   hipLaunchKernelGGL(conv_out1_kernel, dim3(blocks), dim3(TPB), sm, st, a, ps, planes, w, out, L, C, ktaps,

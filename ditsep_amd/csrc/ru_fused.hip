@@ -414,12 +414,13 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
 }
 
 const op16_t* ru_zero_page() {
-  static op16_t* zp = nullptr;
-  if (!zp) {
-    if (hipMalloc((void**)&zp, 4096) != hipSuccess) return nullptr;
-    (void)hipMemset(zp, 0, 4096);
+  static op16_t* zp[64] = {};
+  op16_t*& z = zp[dsn_current_device()];
+  if (!z) {
+    if (hipMalloc((void**)&z, 4096) != hipSuccess) return nullptr;
+    (void)hipMemset(z, 0, 4096);
   }
-  return zp;
+  return z;
 }
 
 template <int P, int F16>
@@ -427,11 +428,10 @@ hipError_t launch_t(const RuDesc& d, hipStream_t st) {
   const op16_t* zp = ru_zero_page();
   if (!zp) return hipErrorOutOfMemory;
   const size_t smem = ((size_t)P * (TL + 56) * C + (size_t)NSTW * P * WTILE) * sizeof(op16_t);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ru_fused_kernel<P, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   const int grid = d.S * ((d.L + TL - 1) / TL);
   hipLaunchKernelGGL((ru_fused_kernel<P, F16>), dim3(grid), dim3(256), smem, st, d, zp);
@@ -445,11 +445,10 @@ hipError_t launch2_t(const RuDesc& d, hipStream_t st) {
   const op16_t* zp = ru_zero_page();
   if (!zp) return hipErrorOutOfMemory;
   const size_t smem = (size_t)LDS2_ELEMS * sizeof(op16_t);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ru_fused2_kernel<F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   const int grid = d.S * ((d.L + TL2 - 1) / TL2);
   hipLaunchKernelGGL((ru_fused2_kernel<F16>), dim3(grid), dim3(512), smem, st, d, zp);
