@@ -798,3 +798,37 @@ def test_dit_balanced_panel_path_vs_oracle(B, T):
     eng = make_engine(cfg, sd, precision=X3)          # split mode: tile kernels, the tight bound
     assert rel_l2(eng.score(xt, t, mix), ref) < 1e-4
     eng.close()
+
+
+def test_igemm_fuzz_shapes(bare):
+    """Seeded random conv / linear shapes through the implicit-GEMM entry (tile kernels and row panels): ragged M,
+    N not a multiple of the tile, K of one to many 32-chunks, taps x dilation x stride, every precision mode."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        prec = [X3, FP16, BF16, FP16X3][case % 4]
+        B = int(rng.integers(1, 4))
+        Cin = 32 * int(rng.integers(1, 9))
+        N = 4 * int(rng.integers(1, 90))
+        taps = int(rng.choice([1, 1, 3, 7]))
+        stride = int(rng.choice([1, 1, 2])) if taps == 1 else 1
+        dil = int(rng.choice([1, 3])) if taps > 1 else 1
+        L = int(rng.integers(5, 400)) * stride
+        g = torch.Generator().manual_seed(1000 + case)
+        a = torch.randn((B, L, Cin), generator=g)
+        w = torch.randn((N, Cin, taps), generator=g) / math.sqrt(Cin * taps)
+        packed = w.permute(0, 2, 1).reshape(N, taps * Cin)
+        pad = dil * (taps - 1) // 2
+        kw = {}
+        if taps == 1 and stride == 1 and case % 3 == 0:        # row-panel kernel on plain linears
+            rows = int(rng.choice([24, 56, 104, 132, 200, 264]))
+            kw = dict(panel_rows=rows, panel_bn=int(rng.choice([128, 256])))
+            if Cin % 64:
+                Cin2 = Cin + 32
+                a = torch.randn((B, L, Cin2), generator=g)
+                w = torch.randn((N, Cin2, 1), generator=g) / math.sqrt(Cin2)
+                packed = w[:, :, 0].contiguous()
+        out = bare[prec].test_igemm(a, packed, taps=taps, tap_dil=dil, in_pad=pad, in_stride=stride,
+                                    rows_per_b=L // stride, **kw)
+        ref = F.conv1d(a.double().transpose(1, 2), w.double(), stride=stride, dilation=dil, padding=pad).transpose(1, 2)
+        assert out.shape == ref.shape, (case, out.shape, ref.shape)
+        assert rel_l2(out, ref) < TOL[prec], (case, prec, B, L, Cin, N, taps, dil, stride, kw)
