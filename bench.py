@@ -2,46 +2,76 @@
 """Headline benchmark: separated utterances/sec on the BASELINE.json C2 workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-A "step" = one pass of the hot path over one batch of synthetic Libri2Mix-shape
-mixtures already resident in HBM as latents: N=30 predictor-corrector sampler
-(1 corrector step, 60 score-network calls, on-device Philox noise) followed by the
-Oobleck decode to waveforms -- the region the reference times
-(src/evaluate_latent.py:273-277).  Mixtures are independent: each rank owns a
-64-mixture shard (weak scaling, BASELINE C3 = 8 x 64) and the only collective is
-one RCCL gather of the separated waveforms to rank 0 per step.
+N > 1: one rank per GPU over RCCL.  Under `python -m torch.distributed.run ... bench.py --gpus N` (how the
+round driver starts it) the ranks read RANK / LOCAL_RANK / WORLD_SIZE; a plain `python bench.py --gpus N`
+starts the same N ranks itself as child processes (ditsep_amd.distributed.launch_ranks) before this process
+has touched the GPU.  It never silently runs fewer ranks than asked for.
+
+A "step" = one pass of the hot path over one batch of synthetic Libri2Mix-shape mixtures already resident in
+HBM as latents: N=30 predictor-corrector sampler (1 corrector step, 60 score-network calls, on-device Philox
+noise) followed by the Oobleck decode to waveforms -- the region the reference times
+(src/evaluate_latent.py:273-277).  Mixtures are independent: each rank owns a 64-mixture shard (weak
+scaling, BASELINE C3 = 8 x 64) and the only data-path collective is one RCCL gather of the separated
+waveforms to rank 0 per step (ditsep_amd.distributed.separate_sharded -- the function the gloo test drives).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from ditsep_amd import native, synthetic  # noqa: E402
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-PRECISIONS = {"bf16": (native.PREC_BF16, "bf16 MFMA operands, fp32 accumulate"),
-              "bf16x3": (native.PREC_BF16X3, "split-bf16 (hi,lo) MFMA operands x3, fp32 accumulate"),
-              "fp16": (native.PREC_FP16, "fp16 MFMA operands, fp32 accumulate"),
-              "fp16x3": (native.PREC_FP16X3, "split-fp16 (hi,lo) MFMA operands x3, fp32 accumulate")}
-PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_MFMA_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / fp16 MFMA
+PEAK_FP8_DENSE_TFLOPS = 5000.0       # ~5 PF dense fp8 MFMA
+PEAK_HBM_GBS = 8000.0                # HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FS, SECONDS, N_STEPS, CORR, SNR, T_EPS = 16000, 4, 30, 1, 0.5, 0.03
 DIT_OUT_GAIN, DIT_SKIP_GAIN, DEC_IN_GAIN, NCSN_OUT_GAIN = 0.002, 0.02, 0.08, 0.01
 
+# call site (dsn_profile_rows) -> what it is, and the kernel name rocprofv3 shows for it at the C2 shape in the
+# headline mode (for cross-checking the table against profiles/*_kernel_stats.csv)
+SITES = {
+    "dit.ff_in": "DiT FF-in GEMM 1024->8192 + SwiGLU (transformer.py:214-288)",
+    "dit.ff_out": "DiT FF-out GEMM 4096->1024 (transformer.py:214-288)",
+    "dit.qkv": "DiT to_qkv GEMM 1024->3072 + RoPE (transformer.py:290-598)",
+    "dit.attn_out": "DiT to_out GEMM 1024->1024 (transformer.py:290-598)",
+    "dit.attention": "DiT softmax(QK^T)V, 16 heads x 64",
+    "dit.residual_norm": "residual add (+ split-K reduce) + LayerNorm -> operand planes",
+    "dit.project_in": "DiT project_in (+ folded preprocess conv)",
+    "dit.project_out": "DiT project_out (+ folded postprocess conv)",
+    "score.time_embed": "timestep features + to_timestep_embed MLP, all steps at once",
+    "vae.residual_unit_fused": "Oobleck ResidualUnit fused (k7 dilated conv + act + 1x1 + residual)",
+    "vae.residual_unit_2gemm": "Oobleck ResidualUnit as two implicit GEMMs (wide layers)",
+    "vae.dec_convT": "Oobleck ConvTranspose1d as 2-tap phase GEMM",
+    "vae.dec_conv_in": "Oobleck decoder first conv",
+    "vae.dec_conv_out": "Oobleck decoder last conv (Cout = 1) + tanh",
+    "ncsnpp.conv": "NCSN++ 3x3 / 1x1 convs and dense layers (implicit GEMM)",
+}
+
+
+def precisions():
+    from ditsep_amd import native
+    return {"bf16": (native.PREC_BF16, "bf16 MFMA operands, fp32 accumulate"),
+            "bf16x3": (native.PREC_BF16X3, "split-bf16 (hi,lo) MFMA operands x3, fp32 accumulate"),
+            "fp16": (native.PREC_FP16, "fp16 MFMA operands, fp32 accumulate"),
+            "fp16x3": (native.PREC_FP16X3, "split-fp16 (hi,lo) MFMA operands x3, fp32 accumulate"),
+            **({"fp8": (native.PREC_FP8, "fp8 e4m3 MFMA operands for the DiT layer GEMMs (per-row scales), "
+                                         "fp16 elsewhere, fp32 accumulate")} if hasattr(native, "PREC_FP8") else {})}
+
 
 def build_engine(device, precision, dcfg, vcfg, dsd, vsd):
+    from ditsep_amd import native, synthetic
     score = dict(score_kind=native.SCORE_DIT, dit_embed_dim=dcfg.embed_dim, dit_depth=dcfg.depth,
                  dit_heads=dcfg.num_heads, latent_dim=dcfg.latent_dim) if isinstance(dcfg, synthetic.DiTConfig) else \
         dict(score_kind=native.SCORE_NCSNPP, ncsn_nf=dcfg.nf, ncsn_ch_mult=dcfg.ch_mult,
@@ -58,29 +88,87 @@ def build_engine(device, precision, dcfg, vcfg, dsd, vsd):
     return eng
 
 
-def cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_mix, y=None):
-    """The CPU restatement of the reference path (oracle/, kind = "port") timed on
-    this host: sampler + decode on `n_mix` mixtures of the same workload."""
+def _cpu_run(score, vsd, vcfg, dcfg, y, noise, L, N):
+    """One pass of the CPU restatement (oracle/, test infrastructure -- here only as the timed baseline)."""
+    import torch
+    from oracle import oobleck as ovae
+    from oracle import sampler as osmp
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        x, nfe = osmp.pc_sample(score, y, noise, osmp.OUVE(N=N), eps=T_EPS, snr=SNR, corrector_steps=CORR,
+                                denoise=True, n_spkrs=dcfg.n_src)
+        wav = ovae.decode_sources(vsd, vcfg, x, L, "decoder.")
+    return time.perf_counter() - t0, wav
+
+
+def cpu_baseline(dcfg, vcfg, dsd, vsd, y_c2, y_c1):
+    """SURVEY 8(d) / BASELINE.md 3: the CPU restatement of the reference path (kind = "port") timed on this
+    host, sampler + decode, 1 warm-up then best of 3: the C2 shape at batch 1 (the headline workload's own
+    mixtures) and config C1 exactly (8 kHz x 4 s, N = 10, batch 1)."""
+    import torch
+    from ditsep_amd import synthetic
     from oracle import dit as odit
     from oracle import ncsnpp as oncs
-    from oracle import oobleck as ovae
     from oracle import sampler as osmp
 
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DITSEP_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    T = (L + (vcfg.hop - L % vcfg.hop)) // vcfg.hop
-    g = torch.Generator().manual_seed(99)
-    y = torch.randn((n_mix, 1, vcfg.latent_dim, T), generator=g) if y is None else y.detach().cpu().float()
-    noise = osmp.draw_noise(g, 1 + N_STEPS * (CORR + 1), (n_mix, dcfg.n_src, vcfg.latent_dim, T))
     score = odit.DiTScore(dsd, dcfg) if isinstance(dcfg, synthetic.DiTConfig) else oncs.NCSNppScore(dsd, dcfg)
-    t0 = time.perf_counter()
-    x, nfe = osmp.pc_sample(score, y, noise, osmp.OUVE(N=N_STEPS), eps=T_EPS, snr=SNR, corrector_steps=CORR,
-                            denoise=True, n_spkrs=dcfg.n_src)
-    wav = ovae.decode_sources(vsd, vcfg, x, L, "decoder.")
-    dt = time.perf_counter() - t0
-    return {"value": n_mix / dt, "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_mix} mixtures of the same C2 workload (N=30, 60 NFE, sampler+decode), "
-                      f"PyTorch-CPU fp32 oracle, {dt:.1f} s"}, y, noise, wav
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for name, y, L, N in (("c2_b1", y_c2, FS * SECONDS, N_STEPS), ("c1", y_c1, 8000 * SECONDS, 10)):
+        y = y.detach().cpu().float()
+        noise = osmp.draw_noise(g, 1 + N * (CORR + 1), (y.shape[0], dcfg.n_src, vcfg.latent_dim, y.shape[-1]))
+        times, wav = [], None
+        for rep in range(4):                      # warm-up + 3
+            dt, wav = _cpu_run(score, vsd, vcfg, dcfg, y, noise, L, N)
+            if rep:
+                times.append(dt)
+            log(f"cpu {name} run {rep}: {dt:.2f} s")
+        out[name] = dict(times=times, best=min(times), noise=noise, wav=wav, y=y, L=L, N=N)
+    c2, c1 = out["c2_b1"], out["c1"]
+    rec = {"value": round(1.0 / c2["best"], 4), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 mixture of the C2 workload (16 kHz x 4 s, N=30, 60 NFE, sampler+decode; batch 1), "
+                     f"PyTorch-CPU fp32 oracle, 1 warm-up + best of 3: {[round(t, 2) for t in c2['times']]} s",
+           "c1": {"value": round(1.0 / c1["best"], 4), "unit": "utt/s",
+                  "sample": f"config C1 exactly: 8 kHz x 4 s (T=16), N=10 (20 NFE), batch 1, sampler+decode, "
+                            f"1 warm-up + best of 3: {[round(t, 2) for t in c1['times']]} s"}}
+    return rec, c2, c1
+
+
+def roofline_rows(prof, fp8_sites=()):
+    """Per call-site roofline rows from the engine's per-launch HIP events (one un-timed step)."""
+    rows = []
+    for r in prof["rows"]:
+        ms = r["ms"]
+        if ms <= 0:
+            continue
+        row = {"site": r["site"], "what": SITES.get(r["site"], ""), "launches": r["launches"],
+               "ms_per_step": round(ms, 3), "avg_launch_us": round(1e3 * ms / r["launches"], 2)}
+        if r["flops"] > 0:
+            peak = PEAK_FP8_DENSE_TFLOPS if r["site"] in fp8_sites else PEAK_MFMA_DENSE_TFLOPS
+            tf = r["flops"] / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=round(tf, 1), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4),
+                       gflop_per_launch=round(r["flops"] / r["launches"] / 1e9, 3))
+        elif r["bytes"] > 0:
+            gbs = r["bytes"] / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                       frac=round(gbs / PEAK_HBM_GBS, 4), mb_per_launch=round(r["bytes"] / r["launches"] / 1e6, 3))
+        if r["flops"] > 0 and r["bytes"] > 0:       # HBM-bound member of the GEMM family (fused ResidualUnit)
+            gbs = r["bytes"] / (ms * 1e-3) / 1e9
+            row["hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def main():
@@ -89,25 +177,49 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="mixtures per GPU")
-    ap.add_argument("--precision", choices=list(PRECISIONS), default="fp16")
-    ap.add_argument("--alt", default="bf16x3,bf16", help="comma list of secondary precisions to also measure")
+    ap.add_argument("--precision", default="fp16")
+    ap.add_argument("--alt", default="bf16x3,bf16,fp8", help="comma list of secondary precisions to also measure")
     ap.add_argument("--score", choices=["dit", "ncsnpp"], default="dit",
                     help="dit: the north-star DiT score network (ditsep.json dims); ncsnpp: the NCSN++ the reference wires in")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="issue decode(i) and sampler(i+1) on separate streams (measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary-precision measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C1 latency / long-form side measurements")
     args = ap.parse_args()
 
+    force_dist = bool(os.environ.get("DITSEP_FORCE_DIST"))     # rehearse the RCCL path with world size 1
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as fresh children (this process has not touched
+        # the GPU: torch is not even imported yet) and relay their exit code
+        from ditsep_amd import distributed
+        import torch
+        have = torch.cuda.device_count()                        # counting devices does not initialise the GPU
+        if have < args.gpus:
+            log(f"--gpus {args.gpus} but only {have} GPU(s) visible: refusing to run fewer ranks than asked for")
+            sys.exit(2)
+        sys.exit(distributed.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    import torch
+    from ditsep_amd import distributed, synthetic
+    PRECISIONS = precisions()
+    if args.precision not in PRECISIONS:
+        log(f"unknown precision {args.precision}")
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+            f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+            f"bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus {args.gpus}`")
+        sys.exit(2)
     dist = None
-    if world > 1 or os.environ.get("DITSEP_FORCE_DIST"):     # DITSEP_FORCE_DIST: rehearse the RCCL path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -133,35 +245,16 @@ def main():
     y = eng.encode(mix, seed=7 + rank)                 # latents resident in HBM before the timed region
     torch.cuda.synchronize()
     log("latents encoded", tuple(y.shape))
-    gather_buf = None
-    if dist is not None and rank == 0:
-        gather_buf = [torch.empty((B, dcfg.n_src, L), device=dev) for _ in range(world)]
-
-    # Two HIP streams: the sampler of batch i+1 (MFMA / L2 bound) is issued while the decode of batch i
-    # (HBM bound) and its gather are still running -- batches are independent, every step still does
-    # all of its work inside the timed region (both streams are drained before the clock stops).
-    s_samp, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    pipelined = args.pipeline
+    # the one data-path collective: buffers and shard sizes fixed before the timed region
+    plan = distributed.ShardPlan(B, dcfg.n_src, L, dev) if dist is not None else None
+    n_ranks = dist.get_world_size() if dist is not None else 1
 
     def step(i, engine=eng):
-        if not pipelined:
-            x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
-                                      denoise=True, seed=(1000 * rank + i) & 0x7FFFFFFF)
-            wav = engine.decode(x, L)
-            if dist is not None:
-                dist.gather(wav, gather_buf, dst=0)
-            return wav, nfe
-        with torch.cuda.stream(s_samp):
-            x, nfe = engine.pc_sample(y, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
-                                      denoise=True, seed=(1000 * rank + i) & 0x7FFFFFFF)
-            ready = s_samp.record_event()
-        s_dec.wait_event(ready)
-        with torch.cuda.stream(s_dec):
-            x.record_stream(s_dec)
-            wav = engine.decode(x, L)
-            if dist is not None:
-                dist.gather(wav, gather_buf, dst=0)
-        return wav, nfe
+        def separate_shard(y_shard):                   # this rank's mixtures: sampler + decode
+            x, _ = engine.pc_sample(y_shard, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS,
+                                    denoise=True, seed=(1000 * rank + i) & 0x7FFFFFFF)
+            return engine.decode(x, L)
+        return distributed.separate_sharded(separate_shard, y, presharded=True, plan=plan)
 
     def timed(k, w, engine=eng):
         # engine setup, not warm-up: the first call per shape sizes the workspace (eager), the second
@@ -170,7 +263,7 @@ def main():
             step(-1 - i, engine)
         for i in range(w):
             step(i, engine)
-        torch.cuda.synchronize()          # device-wide: drains both pipeline streams
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -189,42 +282,56 @@ def main():
         return el
 
     elapsed = timed(args.steps, args.warmup)
-    value = world * B * args.steps / elapsed
+    value = n_ranks * B * args.steps / elapsed
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps -> {value:.2f} utt/s")
 
-    # dominant kernel roofline: per-launch HIP events around every implicit-GEMM launch of one step
+    # roofline: per-launch HIP events (on the launch stream) around every profiled launch of one extra step
     eng.profile_begin()
     step(10_000)
     prof = eng.profile_end()
-    ach = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12
-    # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs over scripts/pmc_workload.py, gfx950 corrections applied by scripts/pmc_summary.py),
-    # weighted like one bench step: N_STEPS*(CORR+1) score calls + one decode.
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.precision}_{args.score}.json")
-    if os.path.exists(pmc_file) and B == 64:
+    table = roofline_rows(prof, fp8_sites=("dit.qkv", "dit.attn_out", "dit.ff_in", "dit.ff_out")
+                          if args.precision == "fp8" else ())
+    fam = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12
+    dom = next((r for r in table if r.get("bound") == "mfma"), None)
+    # HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate
+    # runs over scripts/pmc_workload.py, gfx950 corrections by scripts/pmc_summary.py), taken at the commit
+    # recorded in the file -- not re-measured by this run
+    traffic, traffic_source = None, None
+    pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.precision}_{args.score}.json")
+    if os.path.exists(pmc_file) and B == 64 and dom is not None:
         pm = json.load(open(pmc_file))
-        nfe = N_STEPS * (CORR + 1)
-        launches = nfe * pm["igemm_launches_per_score_call"] + pm["igemm_launches_per_decode"]
-        traffic = round((nfe * pm["score_call_hbm_bytes"] + pm["decode_hbm_bytes"]) / launches)
-    roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
-                "kernel": "igemm_panel_kernel / igemm2_kernel (implicit-GEMM MFMA family, all launches, %s)" % args.precision, "launches_per_step": prof["gemm_launches"],
-                "avg_launch_us": round(1e3 * prof["gemm_ms"] / max(1, prof["gemm_launches"]), 2),
-                "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
-                "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
+        site = pm.get("sites", {}).get(dom["site"])
+        if site:
+            traffic = round(site["hbm_bytes_per_launch"])
+            traffic_source = {"file": os.path.relpath(pmc_file, ROOT), "commit": pm.get("commit"),
+                              "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, replayed from the file",
+                              "score_call_hbm_bytes": pm.get("score_call_hbm_bytes"),
+                              "decode_hbm_bytes": pm.get("decode_hbm_bytes")}
+    roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_MFMA_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "traffic": traffic, "traffic_source": traffic_source}
+    if dom is not None:
+        roofline.update(achieved=dom["achieved"], frac=dom["frac"], peak=dom["peak"],
+                        kernel=f"{dom['site']}: {dom['what']}", launches_per_step=dom["launches"],
+                        avg_launch_us=dom["avg_launch_us"], gflop_per_launch=dom["gflop_per_launch"])
+    roofline["family"] = {"kernel": "implicit-GEMM MFMA family, all launches (igemm_panel / igemm2 / fused ResidualUnit)",
+                          "achieved": round(fam, 2), "frac": round(fam / PEAK_MFMA_DENSE_TFLOPS, 4),
+                          "launches_per_step": prof["gemm_launches"],
+                          "algorithmic_tflop_per_step": round(prof["gemm_flops"] / 1e12, 3),
+                          "gemm_ms_per_step": round(prof["gemm_ms"], 2)}
+    roofline["table"] = table[:10]
+    roofline["note"] = ("per-launch HIP events on the launch stream, graphs bypassed, one extra un-timed step; events add "
+                        "~2 us per launch, so `achieved` reads slightly low vs profiles/*_kernel_stats.csv")
     if prof["hbm_launches"]:
-        # second-largest kernel class: the fused ResidualUnit of the 128-channel decoder layers, HBM bound
         gbs = prof["hbm_bytes"] / (prof["hbm_ms"] * 1e-3) / 1e9
-        roofline["secondary"] = {"kernel": "ru_fused2_kernel (fused Oobleck ResidualUnit, 128 ch)", "bound": "hbm",
-                                 "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                 "frac": round(gbs / 8000.0, 4), "launches_per_step": prof["hbm_launches"],
+        roofline["secondary"] = {"kernel": "ru_fused kernel (fused Oobleck ResidualUnit, 128 ch)", "bound": "hbm",
+                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": prof["hbm_launches"],
                                  "avg_launch_us": round(1e3 * prof["hbm_ms"] / prof["hbm_launches"], 1),
                                  "algorithmic_gb_per_step": round(prof["hbm_bytes"] / 1e9, 2)}
 
     out = {
         "metric": "separated utterances/sec @ N=30, 2-spk 4 s mixtures",
-        "value": round(value, 3), "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "utt/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": f"{args.precision} ({PRECISIONS[args.precision][1]})",
@@ -233,13 +340,14 @@ def main():
                                "(reverse_diffusion + ald, 1 corrector step, 60 NFE) + Oobleck decode, "
                                f"batch={B} per GPU; score function: {score_desc}; "
                                "decoder: Oobleck 128ch x(1,2,4,8,16), strides (2,4,4,8,8), ELU",
-                   "global_batch": world * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
-                   "pipelined_decode": pipelined,
-                   "parallelism": f"dp{world}: batch sharded, one RCCL gather of waveforms per step"},
+                   "global_batch": n_ranks * B, "latent_frames": int(y.shape[-1]), "graphs": not args.no_graphs,
+                   "parallelism": f"dp{n_ranks}: batch sharded, one RCCL gather of waveforms per step",
+                   "precision_note": "BASELINE C2 names bf16; fp16 operands (same MFMA rate, 11-bit mantissa) are the "
+                                     "headline because single-plane bf16 misses the 1e-3 waveform bound (see alt_precision)"},
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and n_ranks == 1:
         # the same step with the encoder included (the reference times sampler + decode only, so this
         # is a secondary figure, never `value`)
         def full_step(i):
@@ -257,46 +365,74 @@ def main():
         el_full = time.perf_counter() - t0
         out["with_encode"] = {"value": round(B * args.steps / el_full, 3), "unit": "utt/s",
                               "ms_per_step": round(1e3 * el_full / args.steps, 2)}
+        # config C1 on the same engine: 8 kHz x 4 s, N = 10, batch 1 -- latency per mixture
+        L1 = 8000 * SECONDS
+        mix1 = synthetic.synthetic_sources(1, dcfg.n_src, L1, 8000, seed=77).sum(1, keepdim=True).to(dev)
+        y1 = eng.encode(mix1, seed=3)
+        if not args.no_extra:
+            def c1_step(i):
+                xx, _ = eng.pc_sample(y1, None, N=10, corrector_steps=CORR, snr=SNR, t_eps=T_EPS, seed=100 + i)
+                return eng.decode(xx, L1)
+            for i in range(4):
+                c1_step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(10):
+                c1_step(10 + i)
+            torch.cuda.synchronize()
+            c1_ms = 1e2 * (time.perf_counter() - t0)
+            out["extra"] = {"c1_latency_ms_per_mixture": round(c1_ms, 2),
+                            "c1": "config C1: 8 kHz x 4 s (T=16), N=10 + 1 corrector (20 NFE), batch 1, sampler + "
+                                  "decode, hipGraph replay, mean of 10"}
         if not args.no_cpu_baseline:
-            n_cpu = 2
             log("cpu baseline (oracle) ...")
-            # the CPU path starts from the same encoded latents of the first synthetic mixtures
-            cb, y_c, noise_c, wav_c = cpu_baseline(dcfg, vcfg, dsd, vsd, L, n_cpu, y=y[:n_cpu])
+            cb, c2, c1 = cpu_baseline(dcfg, vcfg, dsd, vsd, y[:1], y1)
             log("cpu baseline done:", cb["value"], "utt/s on", cb["cores"], "threads")
             out["cpu_baseline"] = cb
-            # live parity of the native path on the very sample the CPU just computed
-            xg, _ = eng.pc_sample(y_c, noise_c, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
-            wg = eng.decode(xg, L).cpu()
-            # BASELINE's second metric: |SI-SDR(build, s) - SI-SDR(CPU path, s)| per mixture under PIT against the
-            # synthetic sources s (random-init weights: the absolute SI-SDR means nothing, the delta is the gate)
+            # live parity of the native path on the very samples the CPU just computed
             from oracle import metrics as omet
-            sdr_g, _ = eng.si_sdr_pit(src[:n_cpu], wg)
-            sdr_c, _ = omet.si_sdr_pit(src[:n_cpu], wav_c)
-            out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": float((wg.double() - wav_c.double()).norm()
-                                                                   / wav_c.double().norm()),
-                             "tolerance": 1e-3,
-                             "si_sdr_delta_db_vs_cpu_fp32": float((sdr_g.mean(-1) - sdr_c).abs().max()),
-                             "si_sdr_tolerance_db": 0.05, "mixtures": n_cpu}
+            par = {}
+            for name, c, s_ref in (("c2_b1", c2, src[:1]), ("c1", c1, None)):
+                xg, _ = eng.pc_sample(c["y"], c["noise"], N=c["N"], corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
+                wg = eng.decode(xg, c["L"]).cpu()
+                par[name] = float((wg.double() - c["wav"].double()).norm() / c["wav"].double().norm())
+                if s_ref is not None:
+                    # BASELINE's second metric: |SI-SDR(build, s) - SI-SDR(CPU path, s)| under PIT against the
+                    # synthetic sources (random-init weights: only the delta is meaningful)
+                    sdr_g, _ = eng.si_sdr_pit(s_ref, wg)
+                    sdr_c, _ = omet.si_sdr_pit(s_ref, c["wav"])
+                    par["si_sdr_delta_db_vs_cpu_fp32"] = float((sdr_g.mean(-1) - sdr_c).abs().max())
+            out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": par["c2_b1"], "rel_l2_waveform_vs_cpu_fp32_c1": par["c1"],
+                             "tolerance": 1e-3, "si_sdr_delta_db_vs_cpu_fp32": par["si_sdr_delta_db_vs_cpu_fp32"],
+                             "si_sdr_tolerance_db": 0.05, "mixtures": 1,
+                             "note": "2-mixture N=30 chain, C4 and C5 parity: tests/test_gpu_configs.py"}
         if not args.no_alt:
             noise = torch.randn((1 + N_STEPS * (CORR + 1), 4, dcfg.n_src, 64, int(y.shape[-1])), device=dev)
             wa = eng.decode(eng.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)
             out["alt_precision"] = []
-            for name in [a for a in args.alt.split(",") if a and a != args.precision]:
+            for name in [a for a in args.alt.split(",") if a and a != args.precision and a in PRECISIONS]:
                 log("secondary precision", name, "...")
                 eng2 = build_engine(local, PRECISIONS[name][0], dcfg, vcfg, dsd, vsd)
                 eng2.enable_graphs(not args.no_graphs)
                 el2 = timed(max(1, args.steps), 3, eng2)
                 wb = eng2.decode(eng2.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR,
                                                 t_eps=T_EPS)[0], L)
-                out["alt_precision"].append({
-                    "dtype": name, "value": round(B * max(1, args.steps) / el2, 3), "unit": "utt/s",
-                    "rel_l2_waveform_vs_headline_mode": float((wb.double() - wa.double()).norm()
-                                                              / wa.double().norm())})
+                rec = {"dtype": name, "value": round(B * max(1, args.steps) / el2, 3), "unit": "utt/s",
+                       "rel_l2_waveform_vs_headline_mode": float((wb.double() - wa.double()).norm()
+                                                                 / wa.double().norm())}
+                if name == "fp8":
+                    eng2.profile_begin()
+                    step(20_000, eng2)
+                    p2 = eng2.profile_end()
+                    rec["roofline_table"] = [r for r in roofline_rows(
+                        p2, fp8_sites=("dit.qkv", "dit.attn_out", "dit.ff_in", "dit.ff_out")) if r["site"].startswith("dit.")][:6]
+                out["alt_precision"].append(rec)
                 eng2.close()
     elif rank == 0:
         out["cpu_baseline"] = None
 
     if rank == 0:
+        out["commit"] = git_head()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

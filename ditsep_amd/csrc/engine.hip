@@ -92,7 +92,16 @@ struct Graph {
 struct ProfRec {
   hipEvent_t a, b;
   double flops;
-  double hbm_bytes = 0;  // > 0: an HBM-bound launch (fused ResidualUnit), algorithmic bytes
+  double hbm_bytes = 0;  // algorithmic HBM bytes of the launch (0 = not stated)
+  const char* tag = "";  // call-site label (static string): rows of dsn_profile_rows
+  bool gemm = true;      // counted in the implicit-GEMM family totals of dsn_profile_end
+  bool hbm_bound = false;  // the HBM-bound member of that family (fused ResidualUnit): dsn_profile_hbm
+};
+
+struct ProfRow {
+  std::string name;
+  double ms = 0, flops = 0, bytes = 0;
+  int64_t launches = 0;
 };
 
 }  // namespace
@@ -134,6 +143,33 @@ struct dsn_ctx {
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   bool profiling = false;
   std::vector<ProfRec> prof;
+  std::vector<ProfRow> prof_rows;  // per call-site aggregation of the last profiled region
+  const char* cur_tag = "";        // label the next profiled launches carry
+  struct Tag {                     // scoped call-site label
+    dsn_ctx* c;
+    const char* prev;
+    Tag(dsn_ctx* ctx, const char* t) : c(ctx), prev(ctx->cur_tag) { c->cur_tag = t; }
+    ~Tag() { c->cur_tag = prev; }
+  };
+  // bracket a non-GEMM launch with events when profiling (algorithmic HBM bytes given by the caller)
+  template <class F>
+  void prof_launch(const char* tag, double bytes, hipStream_t st, F&& f) {
+    if (!profiling) {
+      f();
+      return;
+    }
+    ProfRec pr;
+    HIPCHK(hipEventCreate(&pr.a));
+    HIPCHK(hipEventCreate(&pr.b));
+    pr.flops = 0;
+    pr.hbm_bytes = bytes;
+    pr.tag = tag;
+    pr.gemm = false;
+    HIPCHK(hipEventRecord(pr.a, st));
+    f();
+    HIPCHK(hipEventRecord(pr.b, st));
+    prof.push_back(pr);
+  }
   std::vector<float> tv_host;  // uploaded timestep table signature
   int tv_B = -1;
 
@@ -567,6 +603,7 @@ struct dsn_ctx {
       HIPCHK(hipEventCreate(&pr.a));
       HIPCHK(hipEventCreate(&pr.b));
       pr.flops = 2.0 * (double)d.M * (double)d.N * (double)d.taps * (double)d.Cin;
+      pr.tag = cur_tag;
       HIPCHK(hipEventRecord(pr.a, st));
     }
     static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
@@ -618,6 +655,8 @@ struct dsn_ctx {
       pr.flops = 2.0 * (double)S * (double)L * 128.0 * 128.0 * 8.0;
       // algorithmic HBM bytes: planes in, fp32 residual in, fp32 out (when kept), planes out
       pr.hbm_bytes = (double)S * (double)L * 128.0 * (2.0 * P + 4.0 + (out_f32 ? 4.0 : 0.0) + 2.0 * P);
+      pr.tag = "vae.residual_unit_fused";
+      pr.hbm_bound = true;
       HIPCHK(hipEventRecord(pr.a, st));
     }
     hipError_t e = ru_fused_launch(d, PL, st);
@@ -677,6 +716,7 @@ struct dsn_ctx {
 
     launch_pack_tokens(xt, io, mix, Dl, B, T, nullptr, Up, Mt * din, PL, st);
     {  // X[b, 1+t] = (U + U Wpre^T) Win^T, one folded matrix (fold_dit_io)
+      Tag tg(this, "dit.project_in");
       GemmDesc d = base_desc(Up, Mt * din, pin, B, T, T);
       d.out_f32 = X;
       d.out_bstride = (long)S * D;
@@ -688,6 +728,7 @@ struct dsn_ctx {
       const float* te = time_cache.find(t, B);
       if (!te) {
         float* tmp = wsbuf<float>("dit_te1", (long)B * D);
+        Tag tg(this, "dit.time_embed");
         dit_time_embed(t, B, tmp, st);
         te = tmp;
       }
@@ -722,9 +763,14 @@ struct dsn_ctx {
     const long slab_stride = M * D;
     for (int i = 0; i < cfg.dit_depth; ++i) {
       const DitLayer& L = layers[i];
-      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
-                           st);
+      // algorithmic bytes of the fused reduce + LayerNorm: x in/out (when slabs are pending), slabs in, planes out
+      auto ln_bytes = [&](int np) { return (double)M * D * (4.0 * (np ? 2 : 1) + 4.0 * np + 2.0 * P); };
+      prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
+        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
+                             st);
+      });
       {  // q|k|v operand planes: rotary + 1/sqrt(dh) fused into the epilogue
+        Tag tg(this, "dit.qkv");
         GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
         d.out_planes = QKVp;
         d.out_ps = M * 3 * D;
@@ -740,8 +786,10 @@ struct dsn_ctx {
         }
         run(d, st, qkv_panel);
       }
-      launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st);
+      prof_launch("dit.attention", (double)M * D * 2.0 * P * 4.0, st,
+                  [&] { launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st); });
       {
+        Tag tg(this, "dit.attn_out");
         GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
         int obn = 128, oks = 2;
@@ -761,11 +809,14 @@ struct dsn_ctx {
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
       }
-      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
-                           st);
+      prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
+        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
+                             st);
+      });
       {
         // FF-in through the row-panel kernel: ceil(M/272) equal row panels x 256-column tiles -- for the
         // benchmark shape (M = 2112 -> 8 panels of 264 rows, N = 8192) exactly 256 workgroups, one round.
+        Tag tg(this, "dit.ff_in");
         GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
         d.swiglu = 1;
         d.out_planes = FF;
@@ -781,6 +832,7 @@ struct dsn_ctx {
         run(d, st, use_panel ? 256 : 0);
       }
       {
+        Tag tg(this, "dit.ff_out");
         GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
         static const char* fcfg = getenv("DSN_FF2_CFG");
         int fbn = 256, fks = 4;
@@ -803,9 +855,12 @@ struct dsn_ctx {
       }
     }
     // final residual update + planes of X (no norm before project_out)
-    launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, PL, (int)M, D, 1e-5f, 0,
-                         st);
+    prof_launch("dit.residual_norm", (double)M * D * (8.0 + 4.0 * pend_n + 2.0 * P), st, [&] {
+      launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, nullptr, nullptr, Ap, M * D, PL, (int)M, D, 1e-5f,
+                           0, st);
+    });
     {  // score = o + o Wpost^T with o = X[b, 1+t] Wout^T, one folded matrix
+      Tag tg(this, "dit.project_out");
       GemmDesc d = base_desc(Ap, M * D, pout, B, T, S);
       d.in_pad = -1;
       d.in_bstride = (long)S * D;
@@ -820,7 +875,10 @@ struct dsn_ctx {
   float* score_tokens(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
     if (!finalized) fail(DSN_ESTATE, "weights not finalized");
     if (cfg.score_kind == DSN_SCORE_DIT) return dit_forward(xt, t, mix, B, T, st);
-    if (cfg.score_kind == DSN_SCORE_NCSNPP) return ncsnpp_forward(xt, t, mix, B, T, st);
+    if (cfg.score_kind == DSN_SCORE_NCSNPP) {
+      Tag tg(this, "ncsnpp.conv");
+      return ncsnpp_forward(xt, t, mix, B, T, st);
+    }
     fail(DSN_ESTATE, "no score network configured (score_kind=%d)", cfg.score_kind);
   }
 
@@ -908,6 +966,7 @@ struct dsn_ctx {
       const bool dit = cfg.score_kind == DSN_SCORE_DIT;
       const int width = dit ? cfg.dit_embed_dim : ncs_dense_total;
       float* all = wsbuf<float>("te_all", (long)N * B * width);
+      Tag tg(this, "score.time_embed");
       if (dit) dit_time_embed(tv, N * B, all, st);
       else ncs_time_dense(tv, N * B, all, st);
       time_cache.t0 = tv;
@@ -972,6 +1031,7 @@ struct dsn_ctx {
     launch_pack_tokens(est, Dl, nullptr, 0, S, T, nullptr, zp, (long)S * T * Dl, PL, st);
     long L = T;
     {
+      Tag tg(this, "vae.dec_conv_in");
       GemmDesc d = base_desc(zp, (long)S * T * Dl, dec_in, S, T, T);
       d.in_pad = (dec_in.taps - 1) / 2;
       d.out_planes = pa;
@@ -985,6 +1045,7 @@ struct dsn_ctx {
       const long Lo = L * b.stride;
       const long o_ps = (long)S * Lo * b.cout;
       {  // ConvTranspose1d as a 2-tap phase GEMM
+        Tag tg(this, "vae.dec_convT");
         GemmDesc d = base_desc(pa, a_ps, b.conv, S, (int)L + 1, (int)L);
         d.tap_dil = -1;
         d.out_bstride = Lo * b.cout;
@@ -1005,6 +1066,7 @@ struct dsn_ctx {
           std::swap(pb, ph);
           continue;
         }
+        Tag tg(this, "vae.residual_unit_2gemm");
         {
           GemmDesc d = base_desc(pb, o_ps, r.conv7, S, (int)Lo, (int)Lo);
           d.tap_dil = r.dil;
@@ -1029,8 +1091,10 @@ struct dsn_ctx {
       L = Lo;
     }
     float* wav = wsbuf<float>("dec_wav", (long)S * L);
-    launch_conv_out1(pa, a_ps, PL, dec_out_w, wav, S, (int)L, dec_blocks.back().cout, dec_out_taps,
-                     cfg.vae_final_tanh, st);
+    prof_launch("vae.dec_conv_out", (double)S * L * (dec_blocks.back().cout * 2.0 * P + 4.0), st, [&] {
+      launch_conv_out1(pa, a_ps, PL, dec_out_w, wav, S, (int)L, dec_blocks.back().cout, dec_out_taps,
+                       cfg.vae_final_tanh, st);
+    });
     return wav;
   }
 
@@ -1072,6 +1136,7 @@ struct dsn_ctx {
           std::swap(pa, ph);
           continue;
         }
+        Tag tg(this, "vae.residual_unit_2gemm");
         {
           GemmDesc d = base_desc(pa, a_ps, r.conv7, S, (int)l, (int)l);
           d.tap_dil = r.dil;
@@ -1094,6 +1159,7 @@ struct dsn_ctx {
       const long lo = l / b.stride;
       const long o_ps = (long)S * lo * b.cout;
       {  // strided conv k = 2s
+        Tag tg(this, "vae.enc_strided_conv");
         GemmDesc d = base_desc(pa, a_ps, b.conv, S, (int)lo, (int)l);
         d.in_stride = b.stride;
         d.in_pad = (b.stride + 1) / 2;
@@ -1113,6 +1179,7 @@ struct dsn_ctx {
     }
     float* enc = wsbuf<float>("enc_out", (long)S * l * enc_out.N);
     {
+      Tag tg(this, "vae.enc_conv_out");
       GemmDesc d = base_desc(pa, a_ps, enc_out, S, (int)l, (int)l);
       d.in_pad = (enc_out.taps - 1) / 2;
       d.out_f32 = enc;
@@ -1596,24 +1663,41 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
   return guarded(ctx, [&] {
     HIPCHK(hipDeviceSynchronize());
     double ms = 0, fl = 0;
+    int64_t n_gemm = 0;
     ctx->hbm_ms = ctx->hbm_bytes = 0;
     ctx->hbm_launches = 0;
+    ctx->prof_rows.clear();
+    std::map<std::string, size_t> row_of;
     for (auto& r : ctx->prof) {
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
-      ms += t;
-      fl += r.flops;
-      if (r.hbm_bytes > 0) {
+      if (r.gemm) {
+        ms += t;
+        fl += r.flops;
+        ++n_gemm;
+      }
+      if (r.hbm_bound) {
         ctx->hbm_ms += t;
         ctx->hbm_bytes += r.hbm_bytes;
         ++ctx->hbm_launches;
       }
+      auto it = row_of.find(r.tag);
+      if (it == row_of.end()) {
+        it = row_of.emplace(r.tag, ctx->prof_rows.size()).first;
+        ctx->prof_rows.push_back(ProfRow());
+        ctx->prof_rows.back().name = r.tag;
+      }
+      ProfRow& row = ctx->prof_rows[it->second];
+      row.ms += t;
+      row.flops += r.flops;
+      row.bytes += r.hbm_bytes;
+      ++row.launches;
       (void)hipEventDestroy(r.a);
       (void)hipEventDestroy(r.b);
     }
     if (gemm_ms) *gemm_ms = ms;
     if (gemm_flops) *gemm_flops = fl;
-    if (gemm_launches) *gemm_launches = (int64_t)ctx->prof.size();
+    if (gemm_launches) *gemm_launches = n_gemm;
     ctx->prof.clear();
     ctx->profiling = false;
   });
@@ -1625,6 +1709,24 @@ int dsn_profile_hbm(dsn_ctx* ctx, double* ms, double* bytes, int64_t* launches) 
   if (bytes) *bytes = ctx->hbm_bytes;
   if (launches) *launches = ctx->hbm_launches;
   return DSN_OK;
+}
+
+int dsn_profile_rows(dsn_ctx* ctx, int max_rows, char* names, double* ms, double* flops, double* bytes,
+                     int64_t* launches) {
+  if (!ctx) return DSN_EINVAL;
+  const int n = (int)std::min<size_t>(ctx->prof_rows.size(), (size_t)std::max(0, max_rows));
+  for (int i = 0; i < n; ++i) {
+    const ProfRow& r = ctx->prof_rows[i];
+    if (names) {
+      strncpy(names + (size_t)i * DSN_PROFILE_NAME_LEN, r.name.c_str(), DSN_PROFILE_NAME_LEN - 1);
+      names[(size_t)i * DSN_PROFILE_NAME_LEN + DSN_PROFILE_NAME_LEN - 1] = 0;
+    }
+    if (ms) ms[i] = r.ms;
+    if (flops) flops[i] = r.flops;
+    if (bytes) bytes[i] = r.bytes;
+    if (launches) launches[i] = r.launches;
+  }
+  return (int)ctx->prof_rows.size();
 }
 
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N, int taps,

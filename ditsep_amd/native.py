@@ -27,7 +27,7 @@ EXPORTS = [
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_decode",
     "dsn_encode", "dsn_decode_chunked", "dsn_encode_chunked",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
-    "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_profile_hbm", "dsn_test_igemm",
+    "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_profile_hbm", "dsn_profile_rows", "dsn_test_igemm",
     "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
 ]
 
@@ -102,6 +102,8 @@ def load_library() -> C.CDLL:
     lib.dsn_profile_begin.argtypes = [vp]
     lib.dsn_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_profile_hbm.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.dsn_profile_rows.argtypes = [vp, ci, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.dsn_si_sdr_pit.argtypes = [vp, vp, vp, ci, ci, ci, fp, C.POINTER(ci), vp]
     lib.dsn_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
@@ -319,8 +321,19 @@ class Engine:
         self._check(self.lib.dsn_profile_end(self.ctx, C.byref(ms), C.byref(fl), C.byref(n)), "dsn_profile_end")
         hm, hb, hn = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.dsn_profile_hbm(self.ctx, C.byref(hm), C.byref(hb), C.byref(hn)), "dsn_profile_hbm")
+        nrows = self.lib.dsn_profile_rows(self.ctx, 0, None, None, None, None, None)
+        rows = []
+        if nrows > 0:
+            NL = 48                                     # DSN_PROFILE_NAME_LEN
+            names = C.create_string_buffer(nrows * NL)
+            rms, rfl, rby = ((C.c_double * nrows)() for _ in range(3))
+            rn = (C.c_int64 * nrows)()
+            self.lib.dsn_profile_rows(self.ctx, nrows, names, rms, rfl, rby, rn)
+            for i in range(nrows):
+                nm = names.raw[i * NL:(i + 1) * NL].split(b"\0", 1)[0].decode()
+                rows.append({"site": nm, "ms": rms[i], "flops": rfl[i], "bytes": rby[i], "launches": int(rn[i])})
         return {"gemm_ms": ms.value, "gemm_flops": fl.value, "gemm_launches": n.value,
-                "hbm_ms": hm.value, "hbm_bytes": hb.value, "hbm_launches": hn.value}
+                "hbm_ms": hm.value, "hbm_bytes": hb.value, "hbm_launches": hn.value, "rows": rows}
 
     def si_sdr_pit(self, ref, est):
         """ref, est [B,n,L] -> (si_sdr [B,n] dB, perm [B,n]): est[:, perm[b,i]] matches ref[:, i]."""

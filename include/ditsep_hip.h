@@ -180,6 +180,12 @@ int dsn_profile_end(dsn_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* 
  * also part of the totals above) -- summed kernel time, ALGORITHMIC bytes (operand planes in, fp32 residual in,
  * fp32 and planes out), launch count */
 int dsn_profile_hbm(dsn_ctx* ctx, double* ms, double* bytes, int64_t* launches);
+/* of the same region, per call site ("dit.qkv", "dit.ff_in", "dit.residual_norm", "vae.residual_unit_fused", ...):
+ * summed event time, algorithmic flops and algorithmic HBM bytes (0 where not stated), launch count.  `names` is
+ * max_rows x DSN_PROFILE_NAME_LEN chars.  Returns the number of rows available (may exceed max_rows). */
+#define DSN_PROFILE_NAME_LEN 48
+int dsn_profile_rows(dsn_ctx* ctx, int max_rows, char* names, double* ms, double* flops, double* bytes,
+                     int64_t* launches);
 
 /* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
  * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */

@@ -149,9 +149,11 @@ def _sub(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def gen_vae(ns):
+def gen_vae(ns, channels=8, tag="tiny"):
+    """`channels=32` ("c32") is the smallest width the HIP decoder / encoder kernels take (one 32-channel K chunk),
+    so the GPU tests can compare the native VAE with reference outputs directly, not only through the oracle."""
     for snake in (False, True):
-        cfg = ovae.OobleckConfig(channels=8, use_snake=snake)
+        cfg = ovae.OobleckConfig(channels=channels, use_snake=snake)
         sd = tiny_vae_weights(cfg, 21)
         enc, dec = _ref_vae(ns, cfg)
         enc.load_state_dict(_sub(sd, "encoder."))
@@ -167,8 +169,8 @@ def gen_vae(ns):
             lat = ns.vae_sample(*e.chunk(2, dim=1))[0]
         torch.manual_seed(23)
         vn = torch.randn((2, 64, 2))
-        save(f"vae_tiny_{'snake' if snake else 'elu'}", z=z, wav=wav, wav_in=wav_in, enc_out=e,
-             vae_noise=vn, latent=lat, wsum=checksum(sd), seed=21, channels=8)
+        save(f"vae_{tag}_{'snake' if snake else 'elu'}", z=z, wav=wav, wav_in=wav_in, enc_out=e,
+             vae_noise=vn, latent=lat, wsum=checksum(sd), seed=21, channels=channels)
 
 
 def gen_vae_chunked(ns):
@@ -198,10 +200,10 @@ def gen_vae_chunked(ns):
 CHUNK_CASES = ((16, 4), (16, 5), (15, 0), (45, 6), (20, 10))
 
 
-def gen_e2e(ns):
+def gen_e2e(ns, channels=8, tag="tiny"):
     """encode -> PC sampler (DiT score) -> decode, composed from the reference's
     own pieces exactly as LatentDiffSep.separate does (diffsep_latent.py:471-487)."""
-    vcfg = ovae.OobleckConfig(channels=8)
+    vcfg = ovae.OobleckConfig(channels=channels)
     vsd = tiny_vae_weights(vcfg, 31)
     enc, dec = _ref_vae(ns, vcfg)
     enc.load_state_dict(_sub(vsd, "encoder."))
@@ -228,8 +230,8 @@ def gen_e2e(ns):
                                      eps=0.03, snr=0.5, corrector_steps=1, denoise=True, n_spkrs=2)
         x, nfe = smp()
         wav = dec(x.reshape(B * 2, 64, -1)).reshape(B, 2, -1)[..., :L]
-    save("e2e_tiny", mix=mix, y=y, x=x, wav=wav, nfe=nfe, seed=34, N=N,
-         wsum_vae=checksum(vsd), wsum_dit=checksum(dsd))
+    save(f"e2e_{tag}", mix=mix, y=y, x=x, wav=wav, nfe=nfe, seed=34, N=N,
+         wsum_vae=checksum(vsd), wsum_dit=checksum(dsd), channels=channels)
 
 
 def main():
@@ -242,8 +244,10 @@ def main():
     gen_sampler_variants(ns)
     gen_dit(ns)
     gen_vae(ns)
+    gen_vae(ns, channels=32, tag="c32")
     gen_vae_chunked(ns)
     gen_e2e(ns)
+    gen_e2e(ns, channels=32, tag="c32")
     try:
         from . import make_golden_ncsnpp
         make_golden_ncsnpp.main(save, checksum)

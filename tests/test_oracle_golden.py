@@ -82,9 +82,10 @@ def test_dit_tiny(golden, tag):
     close(out, g["out"])
 
 
+@pytest.mark.parametrize("tag", ["tiny", "c32"])
 @pytest.mark.parametrize("act", ["elu", "snake"])
-def test_vae_tiny(golden, act):
-    g = golden(f"vae_tiny_{act}")
+def test_vae_tiny(golden, act, tag):
+    g = golden(f"vae_{tag}_{act}")
     cfg = ovae.OobleckConfig(channels=int(g["channels"]), use_snake=(act == "snake"))
     sd = tiny_vae_weights(cfg, int(g["seed"]))
     np.testing.assert_allclose(checksum(sd), g["wsum"], rtol=1e-9)
@@ -109,9 +110,10 @@ def test_weight_norm_fold_transposed_axis():
     torch.testing.assert_close(w.flatten(1).norm(dim=1), gg.flatten())
 
 
-def test_e2e_tiny(golden):
-    g = golden("e2e_tiny")
-    vcfg = ovae.OobleckConfig(channels=8)
+@pytest.mark.parametrize("tag", ["tiny", "c32"])
+def test_e2e_tiny(golden, tag):
+    g = golden(f"e2e_{tag}")
+    vcfg = ovae.OobleckConfig(channels=int(g["channels"]))
     vsd = tiny_vae_weights(vcfg, 31)
     dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
     dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
