@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -264,13 +265,15 @@ struct dsn_ctx {
   }
 
   // ---------------------------------------------------------------- weights
+  mutable std::set<std::string> used;  // names finalize() consumed (strict loading: the rest is unexpected)
   const DevTensor& get(const std::string& name) const {
     auto it = raw.find(name);
     if (it == raw.end()) fail(DSN_ESTATE, "missing weight '%s'", name.c_str());
+    used.insert(name);
     return it->second;
   }
   bool has(const std::string& name) const { return raw.count(name) != 0; }
-  float* maybe(const std::string& name) const { return has(name) ? raw.at(name).p : nullptr; }
+  float* maybe(const std::string& name) const { return has(name) ? get(name).p : nullptr; }
 
   std::vector<float> to_host(const std::string& name) const {
     const DevTensor& t = get(name);
@@ -422,7 +425,37 @@ struct dsn_ctx {
     return r;
   }
 
-  void finalize(hipStream_t st) {
+  // Tensors the configured network does not consume.  Known buffers of the reference's modules are allowed
+  // (RotaryEmbedding.inv_freq, BatchNorm counters); anything else under score_model.* / vae.* means the checkpoint
+  // was trained as a different network (cross-attention, adaLN, global conditioning, qk-norm ...): strict mode
+  // refuses it (nn.Module.load_state_dict(strict=True) semantics, diffsep_latent.py loads strictly), non-strict
+  // drops it.  Either way the unused tensors do not stay resident in HBM.
+  void check_unused(bool strict) {
+    auto ends_with = [](const std::string& s, const char* suf) {
+      const size_t n = strlen(suf);
+      return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+    };
+    std::vector<std::string> extra, drop;
+    for (auto& kv : raw) {
+      if (used.count(kv.first)) continue;
+      drop.push_back(kv.first);
+      if (ends_with(kv.first, "inv_freq") || ends_with(kv.first, "num_batches_tracked")) continue;
+      extra.push_back(kv.first);
+    }
+    if (strict && !extra.empty()) {
+      std::string msg;
+      for (size_t i = 0; i < extra.size() && i < 6; ++i) msg += (i ? ", " : "") + extra[i];
+      if (extra.size() > 6) msg += ", ... (+" + std::to_string(extra.size() - 6) + " more)";
+      fail(DSN_ESTATE, "%zu unexpected tensor(s) the configured network does not use: %s", extra.size(), msg.c_str());
+    }
+    for (auto& name : drop) {
+      (void)hipFree(raw[name].p);
+      raw.erase(name);
+    }
+  }
+
+  void finalize(hipStream_t st, bool strict = true) {
+    used.clear();
     if (!allocs.empty()) {  // weights replaced (e.g. EMA <-> raw parameters): drop the old packing, graphs are stale
       HIPCHK(hipDeviceSynchronize());
       for (void* q : allocs) (void)hipFree(q);
@@ -546,6 +579,7 @@ struct dsn_ctx {
       enc_out = pack_conv(ep + "layers." + std::to_string(li + 1) + ".", st);
     }
     HIPCHK(hipStreamSynchronize(st));
+    check_unused(strict);
     finalized = true;
   }
 
@@ -1290,6 +1324,11 @@ dsn_ctx* dsn_create(const dsn_config* cfg) {
       fail(DSN_EINVAL, "precision must be one of DSN_PREC_{BF16,BF16X3,FP16,FP16X3}");
     if (cfg->vae_n_blocks < 0 || cfg->vae_n_blocks > DSN_MAX_VAE_BLOCKS) fail(DSN_EINVAL, "bad vae_n_blocks");
     if (cfg->n_src < 1 || cfg->latent_dim % 32 != 0) fail(DSN_EINVAL, "bad n_src / latent_dim");
+    if (cfg->score_kind == DSN_SCORE_DIT &&
+        (cfg->dit_heads <= 0 || cfg->dit_embed_dim <= 0 || cfg->dit_embed_dim % cfg->dit_heads != 0 ||
+         cfg->dit_embed_dim / cfg->dit_heads != 64))
+      fail(DSN_EINVAL, "DiT: only 64-wide attention heads are implemented (embed_dim %d / %d heads = %d)",
+           cfg->dit_embed_dim, cfg->dit_heads, cfg->dit_heads > 0 ? cfg->dit_embed_dim / cfg->dit_heads : 0);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) fail(DSN_EINVAL, "device %d out of range (%d GPUs)", cfg->device, ndev);
@@ -1347,8 +1386,10 @@ int dsn_load_tensor(dsn_ctx* ctx, const char* name, const float* data, const int
   });
 }
 
-int dsn_finalize_weights(dsn_ctx* ctx) {
-  return guarded(ctx, [&] { ctx->finalize(nullptr); });
+int dsn_finalize_weights(dsn_ctx* ctx) { return dsn_finalize_weights_ex(ctx, 1); }
+
+int dsn_finalize_weights_ex(dsn_ctx* ctx, int strict) {
+  return guarded(ctx, [&] { ctx->finalize(nullptr, strict != 0); });
 }
 
 int dsn_score(dsn_ctx* ctx, const float* xt, const float* t, const float* mix, float* out, int B, int T,

@@ -15,7 +15,7 @@ from typing import Any, Mapping, Optional
 
 import torch
 
-from . import native, sdes
+from . import checkpoint, native, sdes
 
 
 def _get(cfg: Any, path: str, default=None):
@@ -107,13 +107,12 @@ class LatentDiffSep:
         """Reference checkpoint naming: `score_model.*`, `vae.encoder.*`, `vae.decoder.*`
         (non-EMA parameters, as evaluate_latent.py:203-208 uses them)."""
         self.engine.load_state_dict(state_dict)
-        self.engine.finalize()          # raises on a missing tensor: always strict
+        # a missing tensor always raises; with strict (nn.Module's default, and what the reference's loaders use) so
+        # does a tensor the configured network does not consume -- e.g. cross-attention / global-conditioning /
+        # qk-norm weights of a DiT trained with other options, which would otherwise be silently ignored
+        self.engine.finalize(strict=strict)
         self._finalized = True
         return self
-
-    # Names of module BUFFERS in the reference's state_dicts (everything else is a parameter); EMA shadow
-    # parameters follow `parameters()` order, i.e. state_dict order with the buffers skipped.
-    BUFFER_SUFFIXES = ("inv_freq", "num_batches_tracked")
 
     def load_checkpoint(self, ckpt, use_ema: bool = False):
         """Load a checkpoint written by the reference's training loop (reference src/diffsep_latent.py:341-392):
@@ -132,7 +131,7 @@ class LatentDiffSep:
         ema = ckpt.get("ema")
         if ema is not None:
             scope = "" if ckpt.get("trainable_vae", False) else "score_model."
-            names = [k for k in raw if k.startswith(scope) and not k.endswith(self.BUFFER_SUFFIXES)]
+            names = checkpoint.parameter_names(raw.keys(), scope)
             shadow = list(ema["shadow_params"])
             if len(shadow) != len(names):
                 raise ValueError(f"EMA holds {len(shadow)} tensors but the state_dict has {len(names)} parameters "
@@ -146,8 +145,17 @@ class LatentDiffSep:
         self._using_ema = bool(use_ema)
         return self.load_state_dict(self._ema_state if use_ema else raw)
 
-    def to(self, device):
-        return self
+    def to(self, device=None, *args, **kwargs):
+        """nn.Module.to for the one thing it can mean here: the engine lives on the GPU it was created on.  The
+        same device (or a dtype-only / no-op call) returns self; another device is refused loudly rather than
+        silently ignored -- build a new LatentDiffSep(config, device=i) there instead."""
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        dev = torch.device(device)
+        if dev.type == "cuda" and (dev.index is None or dev.index == self.device_index):
+            return self
+        raise RuntimeError(f"LatentDiffSep lives on cuda:{self.device_index}; cannot move it to {dev} "
+                           "(create a new instance with device=<index>)")
 
     def train(self, mode: bool = True, no_ema: bool = False):
         """Reference semantics (src/diffsep_latent.py:356-388): eval mode swaps the EMA weights in unless
@@ -171,7 +179,11 @@ class LatentDiffSep:
 
     # ------------------------------------------------------------------ reference surface
     @torch.no_grad()
-    def encode(self, mix, target=None, vae_noise=None, seed=0, chunked=False, overlap=32, chunk_size=128):
+    def encode(self, mix, target=None, vae_noise=None, seed=None, chunked=False, overlap=32, chunk_size=128):
+        """reference src/diffsep_latent.py:107-118.  `seed=None` draws fresh posterior noise per call (as the
+        reference's randn does); an int makes the draw reproducible."""
+        if seed is None:
+            seed = int(torch.randint(0, 2**31 - 2, (1,)).item())
         y = self.engine.encode(mix, vae_noise, seed=seed, chunked=chunked, overlap=overlap, chunk_size=chunk_size)
         self.max_len_lat = max(self.max_len_lat, y.shape[-1])
         if target is None:
@@ -205,14 +217,17 @@ class LatentDiffSep:
             return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
         M = y.shape[0]
         noise = kwargs.pop("noise", None)
+        seed = kwargs.pop("seed", None)
 
         def batched_sampling_fn():
             samples, ns = [], []
             for i in range(int(math.ceil(M / minibatch))):
                 sl = slice(i * minibatch, (i + 1) * minibatch)
                 nz = None if noise is None else noise[:, sl]
+                # independent draws per minibatch, as the reference's successive randn calls give: an explicit seed
+                # is offset by the minibatch index (the same seed would repeat one Philox stream in every minibatch)
                 sampler = sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y[sl],
-                                              noise=nz, **kwargs)
+                                              noise=nz, seed=None if seed is None else int(seed) + i, **kwargs)
                 s, n = sampler()
                 samples.append(s)
                 ns.append(n)
@@ -223,7 +238,11 @@ class LatentDiffSep:
     @torch.no_grad()
     def separate(self, mix, target_dim=None, latent=False, **kwargs):
         if not latent:
-            mix, _ = self.encode(mix, None, vae_noise=kwargs.pop("vae_noise", None), seed=kwargs.get("seed") or 0)
+            # the reference draws fresh VAE posterior noise on every call (bottleneck.py:57-83): without an explicit
+            # seed, so does this (an explicit seed makes the whole call reproducible)
+            seed = kwargs.get("seed")
+            enc_seed = int(torch.randint(0, 2**31 - 1, (1,)).item()) if seed is None else int(seed)
+            mix, _ = self.encode(mix, None, vae_noise=kwargs.pop("vae_noise", None), seed=enc_seed)
         sampler_kwargs = dict(_get(self.config, "model.sampler", {}) or {})
         sampler_kwargs.update(kwargs)
         sampler = self.get_pc_sampler("reverse_diffusion", "ald", mix, **sampler_kwargs)

@@ -23,7 +23,7 @@ SCORE_NONE, SCORE_DIT, SCORE_NCSNPP = 0, 1, 2
 MAX_VAE_BLOCKS = 8
 
 EXPORTS = [
-    "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights",
+    "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights", "dsn_finalize_weights_ex",
     "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_decode",
     "dsn_encode", "dsn_decode_chunked", "dsn_encode_chunked",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
     lib.dsn_last_error.argtypes = [vp]
     lib.dsn_load_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci, ci]
     lib.dsn_finalize_weights.argtypes = [vp]
+    lib.dsn_finalize_weights_ex.argtypes = [vp, ci]
     lib.dsn_score.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp]
     lib.dsn_ouve_schedule.argtypes = [vp, ci, cf, cf, fp, fp, fp, fp, fp, fp]
     lib.dsn_pc_sample.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, ci, cf, cf, ci, C.POINTER(ci), vp]
@@ -190,8 +191,9 @@ class Engine:
             self._check(self.lib.dsn_load_tensor(self.ctx, (prefix + k).encode(), C.c_void_p(t.data_ptr()),
                                                  shape, t.ndim, int(t.is_cuda)), f"dsn_load_tensor({prefix + k})")
 
-    def finalize(self):
-        self._check(self.lib.dsn_finalize_weights(self.ctx), "dsn_finalize_weights")
+    def finalize(self, strict: bool = True):
+        """strict: tensors the configured network does not consume are an error (load_state_dict(strict=True))."""
+        self._check(self.lib.dsn_finalize_weights_ex(self.ctx, int(strict)), "dsn_finalize_weights")
 
     # ------------------------------------------------------------------ path
     def score(self, xt, t, mix):

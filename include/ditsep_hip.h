@@ -80,6 +80,10 @@ const char* dsn_last_error(const dsn_ctx* ctx);   /* ctx may be NULL after a fai
 int dsn_load_tensor(dsn_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim,
                     int is_device);
 int dsn_finalize_weights(dsn_ctx* ctx);
+/* strict != 0 (what dsn_finalize_weights does): besides a missing tensor, any loaded tensor the configured network
+ * does not consume is an error (DSN_ESTATE, the names in dsn_last_error) -- nn.Module.load_state_dict(strict=True)
+ * semantics; known module buffers (`*.inv_freq`, `*.num_batches_tracked`) are ignored.  strict == 0 drops them. */
+int dsn_finalize_weights_ex(dsn_ctx* ctx, int strict);
 
 /* score = score_model(xt, time_cond, mix)      (LatentDiffSep.forward)
  * xt [B,n_src,D,T], t [B], mix [B,1,D,T] -> out [B,n_src,D,T] */

@@ -234,6 +234,49 @@ def gen_e2e(ns, channels=8, tag="tiny"):
          wsum_vae=checksum(vsd), wsum_dit=checksum(dsd), channels=channels)
 
 
+def gen_state_keys(ns):
+    """state_dict key order and parameters() order of the reference modules a checkpoint of this path holds
+    (DiffusionTransformer incl. its LayerNorm `beta` / rotary `inv_freq` BUFFERS, Oobleck encoder / decoder with
+    SnakeBeta parameters, LatentScoreModelNCSNpp) -- what ditsep_amd.checkpoint.parameter_names must reproduce to
+    match torch_ema's shadow_params (diffsep_latent.py:341-392).  Names only, written as JSON."""
+    import json
+
+    class Holder(torch.nn.Module):      # LatentDiffSep's attribute order: score_model, then vae (diffsep_latent.py:39-45)
+        def __init__(self, score_model, vae):
+            super().__init__()
+            self.score_model = score_model
+            self.vae = vae
+
+    class Vae(torch.nn.Module):         # AudioAutoencoder registers encoder before decoder (autoencoders.py)
+        def __init__(self, enc, dec):
+            super().__init__()
+            self.encoder, self.decoder = enc, dec
+
+    out = {}
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    for snake in (False, True):
+        enc, dec = _ref_vae(ns, ovae.OobleckConfig(channels=8, use_snake=snake))
+        m = Holder(ns.DiffusionTransformer(**dcfg.reference_kwargs()), Vae(enc, dec))
+        out[f"dit_{'snake' if snake else 'elu'}"] = {
+            "state_dict": list(m.state_dict().keys()),
+            "parameters": [k for k, _ in m.named_parameters()],
+            "score_model_parameters": ["score_model." + k for k, _ in m.score_model.named_parameters()]}
+    try:
+        from . import make_golden_ncsnpp
+        nm = make_golden_ncsnpp.reference_model(2)
+        enc, dec = _ref_vae(ns, ovae.OobleckConfig(channels=8))
+        m = Holder(nm, Vae(enc, dec))
+        out["ncsnpp_elu"] = {"state_dict": list(m.state_dict().keys()),
+                             "parameters": [k for k, _ in m.named_parameters()],
+                             "score_model_parameters": ["score_model." + k for k, _ in m.score_model.named_parameters()]}
+    except (ImportError, AttributeError) as e:
+        print("  (ncsnpp state keys skipped:", e, ")")
+    path = os.path.join(OUT, "state_keys.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.set_num_threads(4)
@@ -248,6 +291,7 @@ def main():
     gen_vae_chunked(ns)
     gen_e2e(ns)
     gen_e2e(ns, channels=32, tag="c32")
+    gen_state_keys(ns)
     try:
         from . import make_golden_ncsnpp
         make_golden_ncsnpp.main(save, checksum)

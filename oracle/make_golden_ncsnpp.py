@@ -20,3 +20,11 @@ def main(save, checksum):
         with torch.no_grad():
             out = ref(xt, t, mix)
         save(f"ncsnpp_tiny_{tag}", xt=xt, mix=mix, t=t, out=out, wsum=checksum(sd), seed=41, nf=32, n_src=n_src)
+
+
+def reference_model(n_src: int = 2, nf: int = 32):
+    """A reference LatentScoreModelNCSNpp instance (tiny), for fixtures that only need its structure."""
+    ns = rl.load_ncsnpp()
+    cfg = NCSNppConfig(n_src=n_src, nf=nf)
+    return ns.LatentScoreModelNCSNpp(num_sources=n_src, backbone_args=cfg.reference_backbone_args(),
+                                     max_latent_length=cfg.max_latent_length).eval()

@@ -675,12 +675,28 @@ def test_load_checkpoint_with_ema_selection(tmp_path):
     dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
     dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
     ema_sd = odit.random_dit_weights(dcfg, 77, out_gain=0.005)          # a different set of score weights
-    sd = {"score_model." + k: v for k, v in dsd.items()}
-    sd["score_model.transformer.rotary_pos_emb.inv_freq"] = torch.ones(16)   # a buffer: not among the EMA tensors
+    # key order, buffers (`*.pre_norm.beta`, `*.ff_norm.beta`, `rotary_pos_emb.inv_freq`) and parameters() order exactly
+    # as the reference's DiffusionTransformer(embed 128, depth 2, heads 2) has them (tests/golden/state_keys.json,
+    # captured from the reference by oracle/make_golden.py): torch_ema's shadow_params skip the buffers
+    import json, os
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_keys.json")))["dit_elu"]
+    sd = {}
+    for k in keys["state_dict"]:
+        if not k.startswith("score_model."):
+            continue
+        short = k[len("score_model."):]
+        if short in dsd:
+            sd[k] = dsd[short]
+        elif k.endswith("norm.beta"):
+            sd[k] = torch.zeros(dcfg.embed_dim)
+        else:
+            assert k.endswith("inv_freq"), k
+            sd[k] = torch.ones(16)
+    assert set(dsd) <= {k[len("score_model."):] for k in sd}
     sd.update({"vae." + k: v for k, v in vsd.items()})
+    shadow = [ema_sd[k[len("score_model."):]] for k in keys["score_model_parameters"]]
     ckpt = {"state_dict": sd, "trainable_vae": False,
-            "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": [ema_sd[k] for k in dsd],
-                    "collected_params": None}}
+            "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": shadow, "collected_params": None}}
     path = tmp_path / "last.ckpt"
     torch.save(ckpt, path)
     model = LatentDiffSep(_tiny_config(tmp_path), precision="bf16x3")

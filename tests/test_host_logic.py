@@ -98,3 +98,22 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+
+
+def test_checkpoint_parameter_names_match_reference_module_order():
+    """EMA shadow tensors are matched to names by parameters() order: the classification of state_dict entries into
+    parameters and buffers must reproduce the reference modules' own order (fixture captured from the reference's
+    DiffusionTransformer / Oobleck / LatentScoreModelNCSNpp by oracle/make_golden.py::gen_state_keys)."""
+    import json
+    import os
+
+    from ditsep_amd import checkpoint
+
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_keys.json")))
+    assert set(keys) >= {"dit_elu", "dit_snake", "ncsnpp_elu"}
+    for tag, v in keys.items():
+        assert checkpoint.parameter_names(v["state_dict"], "") == v["parameters"], tag
+        assert checkpoint.parameter_names(v["state_dict"], "score_model.") == v["score_model_parameters"], tag
+    bufs = [k for k in keys["dit_snake"]["state_dict"] if checkpoint.is_buffer(k)]
+    assert len(bufs) == 5 and all(k.startswith("score_model.") for k in bufs)      # 2 layers x 2 betas + inv_freq
+    assert not any(checkpoint.is_buffer(k) for k in keys["dit_snake"]["state_dict"] if k.startswith("vae."))
