@@ -40,8 +40,16 @@ __device__ __forceinline__ float dsn_snake(float v, float alpha, float inv_beta)
   return v + inv_beta * s * s;
 }
 
+// fp16 operands SATURATE at +-65504 (the largest finite fp16) instead of overflowing to inf: one out-of-range
+// activation of a trained checkpoint (SwiGLU hidden units, Snake outputs) then costs its own clamping error, not a
+// row of inf - inf = NaN downstream.  NaN stays NaN (a clamp that hid it would hide bugs).  bf16 has fp32's range.
+#define DSN_F16_MAX 65504.f
+__device__ __forceinline__ float dsn_sat16(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -DSN_F16_MAX, DSN_F16_MAX);
+  return v != v ? v : c;
+}
 __device__ __forceinline__ op16_t to_op16(float v, int f16) {
-  return f16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
+  return f16 ? __builtin_bit_cast(unsigned short, (_Float16)dsn_sat16(v)) : __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 __device__ __forceinline__ float from_op16(op16_t u, int f16) {
   return f16 ? (float)__builtin_bit_cast(_Float16, u) : (float)__builtin_bit_cast(__bf16, u);

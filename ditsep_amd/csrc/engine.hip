@@ -1670,6 +1670,107 @@ int dsn_si_sdr_pit(dsn_ctx* ctx, const float* ref, const float* est, int B, int 
   });
 }
 
+// SI-SDR / SI-SIR / SI-SAR of every estimate against the references (the decomposition of bss_eval with a
+// one-tap, i.e. scale-invariant, distortion filter; evaluate_latent.py:118-136 calls
+// fast_bss_eval.si_bss_eval_sources(ref, est, zero_mean=False, compute_permutation=True, clamp_db=100)):
+//   e_target = <est_j, ref_i> ref_i / |ref_i|^2          (projection on the matched reference)
+//   P est_j  = projection of est_j on span{ref_0 .. ref_{n-1}}   (n x n Gram solve)
+//   e_interf = P est_j - e_target,  e_artif = est_j - P est_j
+//   SI-SDR = |e_target|^2 / |est_j - e_target|^2,  SI-SIR = |e_target|^2 / |e_interf|^2,
+//   SI-SAR = |P est_j|^2 / |e_artif|^2
+// Device: all inner products (two launches of the dots kernel: ref x est and ref x ref), fp64 accumulation;
+// host: the n <= 4 Gram solves and the permutation (perm_by: 0 = best mean SI-SDR, 1 = best mean SI-SIR --
+// bss_eval's convention, "order according to SIR" evaluate_latent.py:124).  Values clamped to +-clamp_db.
+int dsn_si_bss_eval(dsn_ctx* ctx, const float* ref, const float* est, int B, int n, int L, int perm_by, float clamp_db,
+                    float* si_sdr_out, float* si_sir_out, float* si_sar_out, int* perm_out, void* stream) {
+  return guarded(ctx, [&] {
+    if (!ref || !est || B <= 0 || n <= 0 || n > 4 || L <= 0 || perm_by < 0 || perm_by > 1)
+      fail(DSN_EINVAL, "dsn_si_bss_eval: bad arguments (n <= 4, perm_by 0|1)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cnt = (size_t)B * n * n * 3;
+    double* dd = ctx->wsbuf<double>("sibss", (long)cnt * 2);
+    launch_sisdr_dots(ref, est, B, n, L, dd, st);
+    launch_sisdr_dots(ref, ref, B, n, L, dd + cnt, st);
+    std::vector<double> h(cnt * 2);
+    HIPCHK(hipMemcpyAsync(h.data(), dd, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double clamp = clamp_db > 0 ? clamp_db : 1e30, tiny = 1e-300;
+    auto db = [&](double num, double den) {
+      double v = 10.0 * log10(std::max(num, tiny) / std::max(den, tiny));
+      return std::min(clamp, std::max(-clamp, v));
+    };
+    std::vector<int> p(n);
+    for (int b = 0; b < B; ++b) {
+      double G[4][4], X[4][4], ee[4], sdr[4][4], sir[4][4], sar[4];
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const double* v = &h[(((size_t)b * n + i) * n + j) * 3];
+          X[i][j] = v[0];
+          ee[j] = v[2];
+          G[i][j] = h[cnt + (((size_t)b * n + i) * n + j) * 3];
+        }
+      for (int j = 0; j < n; ++j) {
+        // solve G c = X[:, j] by Gaussian elimination with partial pivoting (fp64, n <= 4)
+        double A[4][5];
+        for (int r = 0; r < n; ++r) {
+          for (int c = 0; c < n; ++c) A[r][c] = G[r][c];
+          A[r][n] = X[r][j];
+        }
+        bool singular = false;
+        for (int c = 0; c < n; ++c) {
+          int piv = c;
+          for (int r = c + 1; r < n; ++r)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+          if (fabs(A[piv][c]) < 1e-300) {
+            singular = true;
+            break;
+          }
+          if (piv != c)
+            for (int k = 0; k <= n; ++k) std::swap(A[piv][k], A[c][k]);
+          for (int r = c + 1; r < n; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k <= n; ++k) A[r][k] -= f * A[c][k];
+          }
+        }
+        double cvec[4] = {0, 0, 0, 0}, pe = 0;
+        if (!singular) {
+          for (int r = n - 1; r >= 0; --r) {
+            double acc = A[r][n];
+            for (int k = r + 1; k < n; ++k) acc -= A[r][k] * cvec[k];
+            cvec[r] = acc / A[r][r];
+          }
+          for (int k = 0; k < n; ++k) pe += cvec[k] * X[k][j];  // |P est_j|^2 = c^T G c = c^T x
+        }
+        pe = std::min(std::max(pe, 0.0), ee[j]);
+        sar[j] = db(pe, ee[j] - pe);
+        for (int i = 0; i < n; ++i) {
+          const double et = G[i][i] > 0 ? X[i][j] * X[i][j] / G[i][i] : 0.0;  // |e_target|^2
+          sdr[i][j] = db(et, ee[j] - et);
+          sir[i][j] = db(et, pe - et);
+        }
+      }
+      for (int i = 0; i < n; ++i) p[i] = i;
+      double best = -1e300;
+      std::vector<int> bestp = p;
+      do {
+        double sc = 0;
+        for (int i = 0; i < n; ++i) sc += perm_by ? sir[i][p[i]] : sdr[i][p[i]];
+        if (sc > best) {
+          best = sc;
+          bestp = p;
+        }
+      } while (std::next_permutation(p.begin(), p.end()));
+      for (int i = 0; i < n; ++i) {
+        const size_t o = (size_t)b * n + i;
+        if (si_sdr_out) si_sdr_out[o] = (float)sdr[i][bestp[i]];
+        if (si_sir_out) si_sir_out[o] = (float)sir[i][bestp[i]];
+        if (si_sar_out) si_sar_out[o] = (float)sar[bestp[i]];
+        if (perm_out) perm_out[o] = bestp[i];
+      }
+    }
+  });
+}
+
 // Development hook: copy `count` floats of the named workspace buffer to host memory.
 int dsn_debug_read(dsn_ctx* ctx, const char* name, float* host, int64_t count) {
   return guarded(ctx, [&] {

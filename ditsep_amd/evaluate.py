@@ -1,9 +1,11 @@
 """Evaluation harness with the semantics of the reference's `evaluate_process`
 (reference src/evaluate_latent.py:159-338): per utterance (or batch) encode, then the TIMED region
 sampler + decode (with a device sync, which the reference lacks :273-277), then permutation-solved
-SI-SDR, one result record per utterance with the reference's JSON fields (:294-304) and the mean
-summary (:139-156).  SI-SIR / SI-SAR / PESQ / STOI come from third-party packages that are neither
-vendored nor installed (fast_bss_eval, pesq, pystoi) and are emitted as null."""
+SI-SDR / SI-SIR / SI-SAR on the device (dsn_si_bss_eval: the bss_eval decomposition with a one-tap filter, the
+permutation chosen on SIR as the reference's `fast_bss_eval.si_bss_eval_sources(..., compute_permutation=True)`
+does, :118-124), one result record per utterance with the reference's JSON fields (:294-304) and the mean
+summary (:139-156).  PESQ / STOI come from third-party packages that are neither vendored nor installed
+(pesq, pystoi) and are emitted as null."""
 from __future__ import annotations
 
 import json
@@ -35,10 +37,11 @@ def evaluate_batches(model, batches: Iterable, fs: int, *, N: Optional[int] = No
         x_result = model.decode(x_result, L)
         torch.cuda.synchronize(dev)
         t_proc = time.perf_counter() - t_s
-        si_sdr, perm = model.engine.si_sdr_pit(target, x_result)
+        si_sdr, si_sir, si_sar, perm = model.engine.si_bss_eval(target, x_result, perm_by="sir", clamp_db=100.0)
         B = mix.shape[0]
         for b in range(B):
-            results[idx] = {"batch_idx": idx, "si_sdr": si_sdr[b].tolist(), "si_sir": None, "si_sar": None,
+            results[idx] = {"batch_idx": idx, "si_sdr": si_sdr[b].tolist(), "si_sir": si_sir[b].tolist(),
+                            "si_sar": si_sar[b].tolist(),
                             "pesq": None, "stoi": None, "nfe": nfe, "runtime": t_proc / B, "len_s": L / fs,
                             "perm": perm[b].tolist()}
             idx += 1

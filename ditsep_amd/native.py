@@ -28,7 +28,7 @@ EXPORTS = [
     "dsn_encode", "dsn_decode_chunked", "dsn_encode_chunked",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_profile_hbm", "dsn_profile_rows", "dsn_test_igemm",
-    "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit",
+    "dsn_bench_igemm", "dsn_debug_read", "dsn_si_sdr_pit", "dsn_si_bss_eval",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
                                      C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.dsn_test_igemm.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.dsn_si_sdr_pit.argtypes = [vp, vp, vp, ci, ci, ci, fp, C.POINTER(ci), vp]
+    lib.dsn_si_bss_eval.argtypes = [vp, vp, vp, ci, ci, ci, ci, cf, fp, fp, fp, C.POINTER(ci), vp]
     lib.dsn_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_int64]
     lib.dsn_bench_igemm.argtypes = [vp] + [ci] * 10 + [C.POINTER(C.c_double)]
     for name in EXPORTS:
@@ -347,6 +348,18 @@ class Engine:
                     "dsn_si_sdr_pit")
         return (torch.tensor(list(sdr), dtype=torch.float32).reshape(B, n),
                 torch.tensor(list(perm), dtype=torch.long).reshape(B, n))
+
+    def si_bss_eval(self, ref, est, perm_by: str = "sir", clamp_db: float = 100.0):
+        """ref, est [B,n,L] -> (si_sdr, si_sir, si_sar [B,n] dB, perm [B,n]) with the permutation solved on
+        `perm_by` ("sir" as bss_eval / the reference's evaluate_latent.py:118-124, or "sdr")."""
+        ref, est = _dev32(ref, self.device), _dev32(est, self.device)
+        B, n, L = ref.shape
+        bufs = [(C.c_float * (B * n))() for _ in range(3)]
+        perm = (C.c_int * (B * n))()
+        self._check(self.lib.dsn_si_bss_eval(self.ctx, _ptr(ref), _ptr(est), B, n, L, {"sdr": 0, "sir": 1}[perm_by],
+                                             float(clamp_db), *bufs, perm, self._stream()), "dsn_si_bss_eval")
+        out = [torch.tensor(list(b), dtype=torch.float32).reshape(B, n) for b in bufs]
+        return (*out, torch.tensor(list(perm), dtype=torch.long).reshape(B, n))
 
     def debug_read(self, name: str, shape):
         out = torch.empty(shape, dtype=torch.float32)

@@ -171,6 +171,14 @@ int dsn_separate(dsn_ctx* ctx, const float* mix, const float* vae_noise, const f
 int dsn_si_sdr_pit(dsn_ctx* ctx, const float* ref, const float* est, int B, int n, int L, float* si_sdr_out,
                    int* perm_out, void* stream);
 
+/* SI-SDR, SI-SIR and SI-SAR with the permutation solved: what evaluate_latent.py:118-136 gets from
+ * fast_bss_eval.si_bss_eval_sources(ref, est, zero_mean=False, compute_permutation=True, clamp_db=100).
+ * ref, est [B,n,L] (device) -> si_sdr / si_sir / si_sar [B,n] and perm [B,n] (host; any may be NULL).
+ * perm_by: 0 = permutation with the best mean SI-SDR, 1 = best mean SI-SIR (bss_eval's convention).
+ * clamp_db <= 0: no clamping.  n <= 4. */
+int dsn_si_bss_eval(dsn_ctx* ctx, const float* ref, const float* est, int B, int n, int L, int perm_by, float clamp_db,
+                    float* si_sdr_out, float* si_sir_out, float* si_sar_out, int* perm_out, void* stream);
+
 /* introspection for benchmarks / tests */
 int dsn_enable_graphs(dsn_ctx* ctx, int enable);          /* hipGraph replay of sample/decode */
 int64_t dsn_workspace_bytes(const dsn_ctx* ctx);
