@@ -14,7 +14,7 @@ def __getattr__(name):
     if name == "Engine":
         from .native import Engine
         return Engine
-    if name in ("sdes", "synthetic", "distributed", "native", "latent"):
+    if name in ("sdes", "synthetic", "distributed", "native", "latent", "score_models", "checkpoint", "evaluate"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -99,6 +99,17 @@ class LatentDiffSep:
         self.t_max = self.sde.T
         self.n_src = n_src
         self.engine = native.Engine(**args)
+        # the object `config.model.score_model._target_` names (reference diffsep_latent.py:39), bound to the engine
+        from . import score_models
+        if args["score_kind"] == native.SCORE_DIT:
+            self.score_model = score_models.DiTScoreModel(embed_dim=args["dit_embed_dim"], depth=args["dit_depth"],
+                                                          num_heads=args["dit_heads"]).bind(self.engine)
+        elif args["score_kind"] == native.SCORE_NCSNPP:
+            self.score_model = score_models.LatentScoreModelNCSNpp(
+                num_sources=n_src, backbone_args=dict(_get(sm, "backbone_args", {}) or {}),
+                max_latent_length=args["ncsn_max_latent_length"]).bind(self.engine)
+        else:
+            self.score_model = None
         self.max_len_lat = 0
         self._finalized = False
 

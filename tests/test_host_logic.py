@@ -139,3 +139,21 @@ def test_oracle_si_bss_eval_decomposition_identities():
     assert all(float((a - b).abs().max()) < 1e-6 for a, b in zip(s2[:3], (sdr, sir, sar)))
     _, _, _, p3 = metrics.si_bss_eval(ref, ref[:, [1, 2, 0]])
     assert torch.equal(p3, torch.tensor([[2, 0, 1]] * 2))
+
+
+def test_score_model_config_targets_resolve_and_refuse_unbound_calls():
+    """INTEGRATION.md names `ditsep_amd.score_models.DiTScoreModel` as the `_target_`: it must import, take the
+    documented keywords (what hydra.utils.instantiate would call) and never compute without an engine."""
+    import importlib
+
+    import pytest
+
+    mod = importlib.import_module("ditsep_amd.score_models")
+    m = mod.DiTScoreModel(embed_dim=1024, depth=24, num_heads=16)
+    assert m.kwargs == {"embed_dim": 1024, "depth": 24, "num_heads": 16}
+    with pytest.raises(RuntimeError):
+        m(None, None, None)
+    with pytest.raises(ValueError):
+        mod.DiTScoreModel(embed_dim=1024, depth=2, num_heads=8)        # 128-wide heads: not implemented
+    n = mod.LatentScoreModelNCSNpp(num_sources=2, backbone_args={"nf": 128}, max_latent_length=16)
+    assert n.kwargs["backbone_args"] == {"nf": 128}
