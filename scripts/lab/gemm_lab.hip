@@ -1,0 +1,326 @@
+// Development lab for the DiT layer GEMMs (M = 2112 token rows): standalone timing of main-loop structures and
+// ablations (staging only / compute only) on the real shapes, weights rotated over many buffers so that they come
+// from HBM as in the pipeline (24 layers x 33 MB of weights never stay cached).  Not part of the product library.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o scripts/lab/gemm_lab scripts/lab/gemm_lab.hip
+//   ./gemm_lab                 (prints one line per configuration)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+typedef unsigned short op16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short op16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CHK(x)                                                                            \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      fprintf(stderr, "%s -> %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                            \
+    }                                                                                     \
+  } while (0)
+
+struct Prob {
+  const op16_t* A;  // [M][K]
+  const op16_t* W;  // [N][K]
+  op16_t* C;        // [M][N] fp16 (or [M][N/2] with swiglu)
+  int M, N, K;
+  int panel_rows, tiles_m, tiles_n;
+  int m_fast;
+};
+
+template <int TBK>
+__device__ __forceinline__ int swzk(int row) {
+  return TBK == 32 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
+}
+
+__device__ __forceinline__ f32x4 mfma(const op16x8& w, const op16x8& a, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+}
+
+// MODE 0 full, 1 staging only (no LDS reads / MFMA), 2 compute only (no in-loop staging)
+// WM x WN waves; MT row sub-tiles per panel dealt over the WM wave rows; every wave owns NTW column sub-tiles.
+template <int WM, int WN, int MT, int NTW, int TBK, int NST, int MODE, int SWIGLU>
+__global__ __launch_bounds__(WM* WN * 64, 1) void lab_kernel(const Prob d, const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];
+  constexpr int NWAVES = WM * WN;
+  constexpr int MTW = (MT + WM - 1) / WM;
+  constexpr int TBN = WN * NTW * 16;
+  constexpr int AROWS = MT * 16;
+  constexpr int ROWS = AROWS + TBN;
+  constexpr int STAGE_ELEMS = ROWS * TBK;
+  constexpr int CPR = TBK / 8;
+  constexpr int RPG = 64 / CPR;
+  constexpr int GROUPS = ROWS / RPG;
+  static_assert(ROWS % RPG == 0, "rows must fill whole glds groups");
+  constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;
+  constexpr int REM = GROUPS % NWAVES;
+  constexpr int KS = TBK / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WN, wave_n = wave - wave_m * WN;
+  constexpr int MBASE = MT / WM, MREM = MT % WM;
+  const int my_mt = MBASE + (wave_m < MREM ? 1 : 0);
+  const int my_row0 = 16 * (wave_m * MBASE + min(wave_m, MREM));
+  const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = d.m_fast ? tile % d.tiles_m : tile / d.tiles_n;
+  const int tile_n = d.m_fast ? tile / d.tiles_m : tile - tile_m * d.tiles_n;
+  const int m0 = tile_m * d.panel_rows, n0 = tile_n * TBN;
+  const int m_end = min(m0 + d.panel_rows, d.M);
+  const int nkt = d.K / TBK;
+
+  const int rsub = lane / CPR, cpos = lane % CPR;
+  const op16_t* rptr[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + gi * NWAVES;
+    const bool is_a = g < AROWS / RPG;
+    const int row = (is_a ? g : g - AROWS / RPG) * RPG + rsub;
+    const int gchunk = cpos ^ swzk<TBK>(row);
+    const int idx = (is_a ? m0 : n0) + row;
+    const bool ok = g < GROUPS && (is_a ? idx < m_end : idx < d.N);
+    rptr[gi] = ok ? (is_a ? d.A : d.W) + (long)idx * d.K + gchunk * 8 : nullptr;
+  }
+  const op16_t* zsrc = zero_page + cpos * 8;
+
+  auto issue = [&](int stage, int kt) {
+    op16_t* sbase = lds + stage * STAGE_ELEMS;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      if (gi < my_groups) {
+        const int g = wave + gi * NWAVES;
+        const op16_t* gp = rptr[gi] ? rptr[gi] + kt * TBK : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(sbase + g * RPG * TBK), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[NTW][MTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int fsw = swzk<TBK>(frow);
+  const int a_row_off = (my_row0 + frow) * TBK;
+  const int w_row_off = (AROWS + wave_n * NTW * 16 + frow) * TBK;
+
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2)
+    if (s2 < nkt) issue(s2, s2);
+
+  for (int i = 0; i < nkt; ++i) {
+    const int younger = min(NST - 2, nkt - 1 - i);
+    if (MODE == 2) {
+      if (i == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else if (NST >= 3 && younger >= 1) {
+      // leave `younger` tiles in flight
+      if (younger == 1) {
+        if (REM == 0 || wave < REM)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW - 1) : "memory");
+      } else if (younger == 2) {
+        if (REM == 0 || wave < REM)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GPW) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (GPW - 1)) : "memory");
+      } else {
+        if (REM == 0 || wave < REM)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * GPW) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * (GPW - 1)) : "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (MODE != 2 && i + NST - 1 < nkt) issue((i + NST - 1) % NST, i + NST - 1);
+    if (MODE == 1) continue;
+
+    const op16_t* base = lds + (MODE == 2 ? 0 : (i % NST)) * STAGE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = ((ks * 4 + fchunk) ^ fsw) * 8;
+      op16x8 fw[NTW];
+#pragma unroll
+      for (int k = 0; k < NTW; ++k) fw[k] = *reinterpret_cast<const op16x8*>(base + w_row_off + k * 16 * TBK + coff);
+#pragma unroll
+      for (int tm = 0; tm < MTW; ++tm) {
+        if (tm < my_mt) {
+          const op16x8 fa = *reinterpret_cast<const op16x8*>(base + a_row_off + tm * 16 * TBK + coff);
+#pragma unroll
+          for (int tn = 0; tn < NTW; ++tn) acc[tn][tm] = mfma(fw[tn], fa, acc[tn][tm]);
+        }
+      }
+    }
+  }
+  // epilogue: lane owns 4 consecutive channels (n) of row m = .. + (lane & 15)
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < MTW; ++tm) {
+    const int m = m0 + my_row0 + tm * 16 + (lane & 15);
+    if (tm >= my_mt || m >= m_end) continue;
+    if (SWIGLU) {
+#pragma unroll
+      for (int tn = 0; tn < NTW; tn += 2) {
+        const int n = n0 + wave_n * NTW * 16 + tn * 16 + nq;  // packed: 16 value cols then 16 gate cols
+        if (n >= d.N) continue;
+        const f32x4 v = acc[tn][tm], g = acc[tn + 1][tm];
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(unsigned short, (_Float16)(v[r] * (g[r] / (1.f + __expf(-g[r])))));
+        const int no = (n0 + wave_n * NTW * 16 + tn * 16) / 2 + nq;
+        *reinterpret_cast<uint2*>(d.C + (long)m * (d.N / 2) + no) =
+            uint2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < NTW; ++tn) {
+        const int n = n0 + wave_n * NTW * 16 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const f32x4 v = acc[tn][tm];
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(unsigned short, (_Float16)v[r]);
+        *reinterpret_cast<uint2*>(d.C + (long)m * d.N + n) =
+            uint2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+      }
+    }
+  }
+}
+
+__global__ void fill_kernel(op16_t* p, long n, unsigned seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 15;
+    x *= 2246822519u;
+    x ^= x >> 13;
+    const float v = ((x & 0xffff) / 65536.f - 0.5f) * 0.25f;
+    p[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+  }
+}
+
+struct Bufs {
+  op16_t *A, *C, *zero;
+  std::vector<op16_t*> W;
+};
+
+template <int WM, int WN, int MT, int NTW, int TBK, int NST, int MODE, int SWIGLU>
+float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, int iters) {
+  constexpr int TBN = WN * NTW * 16;
+  const size_t smem = (size_t)NST * (MT * 16 + TBN) * TBK * sizeof(op16_t);
+  if (smem > 160 * 1024) {
+    printf("%-44s smem %zu too large\n", name, smem);
+    return 0;
+  }
+  auto kern = lab_kernel<WM, WN, MT, NTW, TBK, NST, MODE, SWIGLU>;
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  Prob d;
+  d.A = b.A;
+  d.C = b.C;
+  d.M = M;
+  d.N = N;
+  d.K = K;
+  d.panel_rows = panel_rows;
+  d.tiles_m = (M + panel_rows - 1) / panel_rows;
+  d.tiles_n = (N + TBN - 1) / TBN;
+  d.m_fast = 1;
+  const int grid = d.tiles_m * d.tiles_n;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) {
+    d.W = b.W[w % b.W.size()];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, 0, d, b.zero);
+  }
+  CHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) {
+    d.W = b.W[i % b.W.size()];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, 0, d, b.zero);
+  }
+  CHK(hipEventRecord(e1, 0));
+  CHK(hipEventSynchronize(e1));
+  CHK(hipGetLastError());
+  float ms = 0;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = 1e3 * ms / iters;
+  const double tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  const double stage_gb = (double)grid * (MT * 16 + TBN) * K * 2.0 / 1e9;
+  printf("%-44s grid %4d wg %4d smem %6zu  %7.2f us  %6.0f TF  staged %.0f MB = %.1f GB/s/CU\n", name, grid, WM * WN * 64,
+         smem, us, MODE == 1 ? 0.0 : tf, stage_gb * 1e3, stage_gb / (us * 1e-6) / grid);
+  fflush(stdout);
+  return (float)us;
+}
+
+int main(int argc, char** argv) {
+  const int M = 2112;
+  const int iters = 48;
+  const int NW = 24;  // rotate over this many weight buffers
+  Bufs b;
+  const long maxA = (long)M * 4096, maxW = 8192L * 1024, maxC = (long)M * 8192;
+  CHK(hipMalloc((void**)&b.A, maxA * 2));
+  CHK(hipMalloc((void**)&b.C, maxC * 2));
+  CHK(hipMalloc((void**)&b.zero, 4096));
+  CHK(hipMemset(b.zero, 0, 4096));
+  fill_kernel<<<1024, 256>>>(b.A, maxA, 1);
+  for (int i = 0; i < NW; ++i) {
+    op16_t* w;
+    CHK(hipMalloc((void**)&w, maxW * 2));
+    fill_kernel<<<1024, 256>>>(w, maxW, 100 + i);
+    b.W.push_back(w);
+  }
+  CHK(hipDeviceSynchronize());
+  const char* only = argc > 1 ? argv[1] : "";
+  auto want = [&](const char* tag) { return only[0] == 0 || strstr(tag, only) != nullptr; };
+
+#define RUN(tag, WM, WN, MT, NTW, BK, NST, MODE, SW, M_, N_, K_, PR) \
+  if (want(tag)) run_cfg<WM, WN, MT, NTW, BK, NST, MODE, SW>(tag, b, M_, N_, K_, PR, iters);
+
+  // ---- FF-in: N = 8192 (packed value|gate), K = 1024, 8 panels x 264 rows x 32 column tiles = 256 WGs
+  RUN("ffin 16w 4x4 mt17 bk64 nst2 full", 4, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
+  RUN("ffin 16w 4x4 mt17 bk64 nst2 stage-only", 4, 4, 17, 4, 64, 2, 1, 1, M, 8192, 1024, 264)
+  RUN("ffin 16w 4x4 mt17 bk64 nst2 compute-only", 4, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
+  RUN("ffin 16w 4x4 mt17 bk32 nst4 full", 4, 4, 17, 4, 32, 4, 0, 1, M, 8192, 1024, 264)
+  RUN("ffin 16w 4x4 mt17 bk32 nst4 stage-only", 4, 4, 17, 4, 32, 4, 1, 1, M, 8192, 1024, 264)
+  RUN("ffin 16w 4x4 mt17 bk32 nst3 full", 4, 4, 17, 4, 32, 3, 0, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 2x4 mt17 bk64 nst2 full", 2, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 2x4 mt17 bk64 nst2 compute-only", 2, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 2x4 mt17 bk32 nst4 full", 2, 4, 17, 4, 32, 4, 0, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 2x4 mt17 bk32 nst4 stage-only", 2, 4, 17, 4, 32, 4, 1, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 2x4 mt17 bk32 nst4 compute-only", 2, 4, 17, 4, 32, 4, 2, 1, M, 8192, 1024, 264)
+  // ---- QKV: N = 3072, K = 1024, 21 panels x 104 rows x 12 column tiles = 252 WGs
+  RUN("qkv 16w 4x4 mt7 bk64 nst3 full", 4, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
+  RUN("qkv 16w 4x4 mt7 bk64 nst3 stage-only", 4, 4, 7, 4, 64, 3, 1, 0, M, 3072, 1024, 104)
+  RUN("qkv 16w 4x4 mt7 bk64 nst3 compute-only", 4, 4, 7, 4, 64, 3, 2, 0, M, 3072, 1024, 104)
+  RUN("qkv 16w 4x4 mt7 bk64 nst4 full", 4, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
+  RUN("qkv 8w 2x4 mt7 bk64 nst4 full", 2, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
+  RUN("qkv 4w 1x4 mt7 bk64 nst4 full", 1, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
+  // ---- out-proj without split-K: N = 1024, K = 1024: 32 panels x 66 rows x 8 column tiles(128) = 256 WGs
+  RUN("out 8w 2x4 mt5 ntw2 bk64 nst4 full (66x128)", 2, 4, 5, 2, 64, 4, 0, 0, M, 1024, 1024, 66)
+  RUN("out 4w 1x4 mt5 ntw2 bk64 nst4 full (66x128)", 1, 4, 5, 2, 64, 4, 0, 0, M, 1024, 1024, 66)
+  RUN("out 4w 1x4 mt5 ntw2 bk64 nst4 stage-only", 1, 4, 5, 2, 64, 4, 1, 0, M, 1024, 1024, 66)
+  RUN("out 4w 2x2 mt5 ntw4 bk64 nst4 full (66x128)", 2, 2, 5, 4, 64, 4, 0, 0, M, 1024, 1024, 66)
+  RUN("out 8w 2x4 mt9 ntw1 bk64 nst4 full (132x64)", 2, 4, 9, 1, 64, 4, 0, 0, M, 1024, 1024, 132)
+  // ---- FF-out without split-K: N = 1024, K = 4096
+  RUN("ffout 8w 2x4 mt5 ntw2 bk64 nst4 full (66x128)", 2, 4, 5, 2, 64, 4, 0, 0, M, 1024, 4096, 66)
+  RUN("ffout 4w 1x4 mt5 ntw2 bk64 nst4 full (66x128)", 1, 4, 5, 2, 64, 4, 0, 0, M, 1024, 4096, 66)
+  RUN("ffout 4w 1x4 mt5 ntw2 bk64 nst4 stage-only", 1, 4, 5, 2, 64, 4, 1, 0, M, 1024, 4096, 66)
+  RUN("ffout 4w 2x2 mt5 ntw4 bk64 nst4 full (66x128)", 2, 2, 5, 4, 64, 4, 0, 0, M, 1024, 4096, 66)
+  RUN("ffout 4w 2x2 mt5 ntw4 bk128 nst3 full (66x128)", 2, 2, 5, 4, 128, 3, 0, 0, M, 1024, 4096, 66)
+  return 0;
+}
