@@ -23,9 +23,55 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// Store one query's output features: this lane holds features dt*16 + 4g + r (dt < NDT) of the query's head.
+// 16-bit planes, or -- o8s != null -- fp8 (MX): `out` is then the e4m3 byte tensor [rows][D], o8s the E8M0 scales
+// [rows][D/32]; a 32-feature block is a pair of dt tiles across the 4 lane groups that share the query.
+template <int P, int F16, int NDT>
+__device__ __forceinline__ void store_query_out(op16_t* __restrict__ out, long out_ps, unsigned char* __restrict__ o8s,
+                                                long row, int D, int col0, int g, const f32x4 (&oacc)[NDT], float inv) {
+  if (o8s) {
+    unsigned char* out8 = reinterpret_cast<unsigned char*>(out);
+#pragma unroll
+    for (int dp = 0; dp < NDT / 2; ++dp) {
+      f32x4 v[2];
+      float amax = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        v[u] = oacc[2 * dp + u] * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(v[u][r]));
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int k = dsn_mx_exp(amax);
+      const float sc = dsn_pow2(-k);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        *reinterpret_cast<unsigned*>(out8 + row * D + col0 + (2 * dp + u) * 16 + 4 * g) = dsn_fp8x4(v[u] * sc);
+      if (g == 0) o8s[row * (D >> 5) + ((col0 + dp * 32) >> 5)] = (unsigned char)(k + 127);
+    }
+    return;
+  }
+  const long obase = row * D + col0 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    op16x4 hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      op16_t a, c;
+      dsn_split(oacc[dt][r] * inv, a, c, F16);
+      hi[r] = a;
+      lo[r] = c;
+    }
+    *reinterpret_cast<op16x4*>(out + obase + dt * 16) = hi;
+    if (P == 2) *reinterpret_cast<op16x4*>(out + out_ps + obase + dt * 16) = lo;
+  }
+}
+
 template <int P, int F16, int NKT, int DH>
 __global__ __launch_bounds__(512) void attention_mfma_kernel(const op16_t* __restrict__ qkv, long ps,
-                                                             op16_t* __restrict__ out, long out_ps, int S, int H) {
+                                                             op16_t* __restrict__ out, long out_ps, int S, int H,
+                                                             unsigned char* __restrict__ o8s) {
   // blockDim.x / 64 waves per workgroup: they stage V once and each take query tiles of the same (item, head)
   extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][nkt*16][DH]
   const int lane = threadIdx.x & 63;
@@ -181,25 +227,9 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const op16_t* __res
         }
       }
     }
-    // ---- normalise + store planes: query qt*16 + r16, features dt*16 + 4g + r --------
+    // ---- normalise + store: query qt*16 + r16, features dt*16 + 4g + r --------
     const int qi = qt * 16 + r16;
-    if (qi < S) {
-      const float inv = 1.f / lsum;
-      const long obase = ((long)b * S + qi) * D + h * DH + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        op16x4 hi, lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          op16_t a, c;
-          dsn_split(oacc[dt][r] * inv, a, c, F16);
-          hi[r] = a;
-          lo[r] = c;
-        }
-        *reinterpret_cast<op16x4*>(out + obase + dt * 16) = hi;
-        if (P == 2) *reinterpret_cast<op16x4*>(out + out_ps + obase + dt * 16) = lo;
-      }
-    }
+    if (qi < S) store_query_out<P, F16, NDT>(out, out_ps, o8s, (long)b * S + qi, D, h * DH, g, oacc, 1.f / lsum);
   }
 }
 
@@ -209,7 +239,8 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const op16_t* __res
 // with S.  One wave per (item, head, 16-query tile).
 template <int P, int F16, int DH>
 __global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __restrict__ qkv, long ps,
-                                                            op16_t* __restrict__ out, long out_ps, int S, int H) {
+                                                            op16_t* __restrict__ out, long out_ps, int S, int H,
+                                                            unsigned char* __restrict__ o8s) {
   constexpr int KBT = 8;         // key tiles per block
   constexpr int KB = KBT * 16;   // keys per block
   extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][KB][DH]
@@ -331,28 +362,13 @@ __global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __rest
       }
     }
     const int qi = qt * 16 + r16;
-    if (qi < S) {
-      const float inv = 1.f / l;
-      const long obase = ((long)b * S + qi) * D + h * DH + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        op16x4 hi, lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          op16_t a, c;
-          dsn_split(oacc[dt][r] * inv, a, c, F16);
-          hi[r] = a;
-          lo[r] = c;
-        }
-        *reinterpret_cast<op16x4*>(out + obase + dt * 16) = hi;
-        if (P == 2) *reinterpret_cast<op16x4*>(out + out_ps + obase + dt * 16) = lo;
-      }
-    }
+    if (qi < S) store_query_out<P, F16, NDT>(out, out_ps, o8s, (long)b * S + qi, D, h * DH, g, oacc, 1.f / l);
   }
 }
 
 template <int P, int F16, int DH>
-void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S, int H, hipStream_t st) {
+void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S, int H, unsigned char* o8s,
+              hipStream_t st) {
   const int nkt = (S + 15) / 16;
   if (nkt > 16) {  // more than 256 keys: blocked keys + online softmax
     const size_t sml = (size_t)P * 128 * DH * sizeof(op16_t);
@@ -362,13 +378,13 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, nkt), dim3(64), sml, st, qkv, ps, out, out_ps, S,
-                       H);
+                       H, o8s);
     return;
   }
   const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);
   if (nkt <= 4) {
     hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out, out_ps,
-                       S, H);
+                       S, H, o8s);
   } else {
     static std::atomic<unsigned long long> attr{0};
     if (dsn_first_use_on_device(attr)) {
@@ -378,27 +394,28 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
     // wide heads stage a large V block (DH * nkt * 32 B): share it between the query tiles' waves
     const int W = DH >= 128 ? (nkt >= 8 ? 8 : (nkt >= 4 ? 4 : 1)) : 1;
     hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sm, st,
-                       qkv, ps, out, out_ps, S, H);
+                       qkv, ps, out, out_ps, S, H, o8s);
   }
 }
 
 template <int DH>
-void launch_dh(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, hipStream_t st) {
+void launch_dh(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, unsigned char* o8s,
+               hipStream_t st) {
   const int P = PL_COUNT(pl), f16 = PL_F16(pl);
-  if (P == 1 && !f16) launch_t<1, 0, DH>(qkv, ps, out, out_ps, B, S, H, st);
-  else if (P == 2 && !f16) launch_t<2, 0, DH>(qkv, ps, out, out_ps, B, S, H, st);
-  else if (P == 1) launch_t<1, 1, DH>(qkv, ps, out, out_ps, B, S, H, st);
-  else launch_t<2, 1, DH>(qkv, ps, out, out_ps, B, S, H, st);
+  if (P == 1 && !f16) launch_t<1, 0, DH>(qkv, ps, out, out_ps, B, S, H, o8s, st);
+  else if (P == 2 && !f16) launch_t<2, 0, DH>(qkv, ps, out, out_ps, B, S, H, o8s, st);
+  else if (P == 1) launch_t<1, 1, DH>(qkv, ps, out, out_ps, B, S, H, o8s, st);
+  else launch_t<2, 1, DH>(qkv, ps, out, out_ps, B, S, H, o8s, st);
 }
 
 }  // namespace
 
 // dh = head width (64: DiT; 64/128/256: the single-head NCSN++ attention blocks)
 int launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, int dh,
-                          hipStream_t st) {
-  if (dh == 64) launch_dh<64>(qkv, ps, out, out_ps, pl, B, S, H, st);
-  else if (dh == 128) launch_dh<128>(qkv, ps, out, out_ps, pl, B, S, H, st);
-  else if (dh == 256) launch_dh<256>(qkv, ps, out, out_ps, pl, B, S, H, st);
+                          hipStream_t st, unsigned char* out_fp8_scale) {
+  if (dh == 64) launch_dh<64>(qkv, ps, out, out_ps, pl, B, S, H, out_fp8_scale, st);
+  else if (dh == 128) launch_dh<128>(qkv, ps, out, out_ps, pl, B, S, H, out_fp8_scale, st);
+  else if (dh == 256) launch_dh<256>(qkv, ps, out, out_ps, pl, B, S, H, out_fp8_scale, st);
   else return -1;
   return 0;
 }

@@ -60,6 +60,44 @@ __device__ __forceinline__ void dsn_split(float v, op16_t& hi, op16_t& lo, int f
   lo = to_op16(v - from_op16(hi, f16), f16);
 }
 
+// ---- fp8 operands (DSN_PREC_FP8): OCP e4m3 data with one E8M0 scale byte per 32 consecutive K-elements of a row
+// (the MX block format v_mfma_scale_f32_16x16x128_f8f6f4 consumes): value = fp8 * 2^(byte - 127).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#define DSN_FP8_MAX 448.f
+// k with 2^k >= amax / 448 (so that amax * 2^-k fits e4m3), clamped to the normal-float exponent range
+__device__ __forceinline__ int dsn_mx_exp(float amax) {
+  const unsigned u = __builtin_bit_cast(unsigned, amax * (1.f / DSN_FP8_MAX));
+  const int k = (int)((u >> 23) & 0xffu) - 127 + ((u & 0x7fffffu) ? 1 : 0);
+  return min(max(k, -126), 126);
+}
+__device__ __forceinline__ float dsn_pow2(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+// 4 floats -> 4 saturated e4m3 bytes (byte r = element r)
+__device__ __forceinline__ unsigned dsn_fp8x4(const f32x4& v) {
+  float c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float m = __builtin_amdgcn_fmed3f(v[r], -DSN_FP8_MAX, DSN_FP8_MAX);
+    c[r] = v[r] != v[r] ? v[r] : m;
+  }
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+  return (unsigned)w;
+}
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 x fp8): D[n][m] += sum_k w[n][k] a[m][k] 2^(sw-127) 2^(sa-127).
+// Operand lane map (probed on gfx950, scripts/lab/mx_probe.hip): lane (r = lane & 15, q = lane >> 4) holds row r,
+// bytes k = 16q .. 16q+15 in registers 0-3 and k = 64+16q .. 64+16q+15 in registers 4-7 -- the same two 16-byte
+// chunks (q, 4 + q) of a 128-byte row that the two 16-bit k-steps of a 64-element tile read; its scale operand
+// (byte 0) applies to the 32-element block q of row r.
+__device__ __forceinline__ f32x4 mfma_mx8(const op16x8& w_lo, const op16x8& w_hi, const op16x8& a_lo, const op16x8& a_hi,
+                                          const f32x4& c, int sw, int sa) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const i32x4 wl = __builtin_bit_cast(i32x4, w_lo), wh = __builtin_bit_cast(i32x4, w_hi);
+  const i32x4 al = __builtin_bit_cast(i32x4, a_lo), ah = __builtin_bit_cast(i32x4, a_hi);
+  const i32x8 w = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+  const i32x8 a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 0, 0, sw, 0, sa);
+}
+
 // one v_mfma_f32_16x16x32 on raw 16-bit operand fragments: D[n][m] += sum_k w[n][k] a[m][k]
 template <int F16>
 __device__ __forceinline__ f32x4 mfma16(const op16x8& w, const op16x8& a, const f32x4& c) {

@@ -66,9 +66,17 @@ struct ActP {  // producer-side activation
   int mod = 1;
 };
 
+struct Packed8 {  // fp8 (MX) packed Linear weight: e4m3 bytes [N][K] + E8M0 block scales [N][K/32]
+  unsigned char* w = nullptr;
+  unsigned char* s = nullptr;
+  int N = 0, K = 0;
+  float* bias = nullptr;
+};
+
 struct DitLayer {
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
   Packed qkv, out, ff1, ff2;
+  Packed8 qkv8, out8, ff1_8, ff2_8;  // DSN_PREC_FP8
 };
 
 struct ResUnit {
@@ -112,6 +120,7 @@ struct dsn_ctx {
   std::string err;
   int P = 2;   // operand planes
   int PL = 2;  // DSN_PL(P, fp16 flag) as the kernels take it
+  bool fp8 = false;  // DSN_PREC_FP8: DiT layer GEMMs on fp8 (MX) operands, the rest single-plane fp16
   bool finalized = false;
   bool use_graphs = false;
   double hbm_ms = 0, hbm_bytes = 0;  // HBM-bound launches of the last profiled region (dsn_profile_hbm)
@@ -352,6 +361,29 @@ struct dsn_ctx {
     return p;
   }
 
+  Packed8 pack_linear_fp8(const std::string& wname, const std::string& bname, bool swiglu, hipStream_t st) {
+    const DevTensor& w = get(wname);
+    if (w.shape.size() < 2) fail(DSN_EINVAL, "%s: expected a matrix", wname.c_str());
+    Packed8 p;
+    p.N = (int)w.shape[0];
+    p.K = (int)(w.numel / w.shape[0]);
+    if (p.K % 128 != 0) fail(DSN_EINVAL, "%s: fp8 GEMMs need K %% 128 == 0 (got %d)", wname.c_str(), p.K);
+    p.w = (unsigned char*)dmalloc((size_t)p.N * p.K);
+    p.s = (unsigned char*)dmalloc((size_t)p.N * (p.K / 32));
+    launch_pack_weight_fp8(w.p, p.w, p.s, p.N, p.K, swiglu ? 1 : 0, st);
+    if (!bname.empty() && has(bname)) {
+      const DevTensor& b = get(bname);
+      if (b.numel != p.N) fail(DSN_EINVAL, "%s: bias size mismatch", bname.c_str());
+      if (swiglu) {
+        p.bias = (float*)dmalloc(sizeof(float) * p.N);
+        launch_pack_bias_swiglu(b.p, p.bias, p.N, st);
+      } else {
+        p.bias = b.p;
+      }
+    }
+    return p;
+  }
+
   // weight-normed Conv1d [Cout][Cin][kw] (or plain `weight`) -> [Cout][kw*Cin]
   Packed pack_conv(const std::string& prefix, hipStream_t st) {
     const bool wn = has(prefix + "weight_v");
@@ -481,6 +513,13 @@ struct dsn_ctx {
         L.be1 = maybe(lp + "pre_norm.beta");
         L.g2 = get(lp + "ff_norm.gamma").p;
         L.be2 = maybe(lp + "ff_norm.beta");
+        if (fp8) {
+          L.qkv8 = pack_linear_fp8(lp + "self_attn.to_qkv.weight", "", false, st);
+          L.out8 = pack_linear_fp8(lp + "self_attn.to_out.weight", "", false, st);
+          L.ff1_8 = pack_linear_fp8(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
+          L.ff2_8 = pack_linear_fp8(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
+          continue;
+        }
         L.qkv = pack_linear(lp + "self_attn.to_qkv.weight", "", false, st);
         L.out = pack_linear(lp + "self_attn.to_out.weight", "", false, st);
         L.ff1 = pack_linear(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
@@ -651,6 +690,41 @@ struct dsn_ctx {
                               d.M, d.N, d.Cin, d.taps);
   }
 
+  // descriptor of an fp8 (MX) row-major GEMM: A8 [M][K] bytes + scales [M][K/32], weight w
+  GemmDesc fp8_desc(const unsigned char* A8, const unsigned char* SA, const Packed8& w, int M) {
+    Packed pk;
+    pk.w = reinterpret_cast<op16_t*>(w.w);
+    pk.ps = 0;
+    pk.N = w.N;
+    pk.Cin = w.K / 2;  // byte pairs
+    pk.K = w.K / 2;
+    pk.taps = 1;
+    pk.bias = w.bias;
+    pk.bias_mod = w.N;
+    GemmDesc d = base_desc(reinterpret_cast<const op16_t*>(A8), 0, pk, 1, M, M);
+    d.a_scale = SA;
+    d.w_scale = w.s;
+    d.mx_kblocks = w.K / 32;
+    return d;
+  }
+  void run_fp8(const GemmDesc& d, hipStream_t st, int bn) {
+    ProfRec pr;
+    if (profiling) {
+      HIPCHK(hipEventCreate(&pr.a));
+      HIPCHK(hipEventCreate(&pr.b));
+      pr.flops = 2.0 * (double)d.M * (double)d.N * 2.0 * (double)d.Cin;
+      pr.tag = cur_tag;
+      HIPCHK(hipEventRecord(pr.a, st));
+    }
+    hipError_t e = igemm_panel_fp8_launch(d, bn, st);
+    if (profiling) {
+      HIPCHK(hipEventRecord(pr.b, st));
+      prof.push_back(pr);
+    }
+    if (e != hipSuccess) fail(DSN_EHIP, "fp8 igemm launch failed: %s (M=%d N=%d K=%d rows=%d bn=%d)", hipGetErrorString(e),
+                              d.M, d.N, 2 * d.Cin, d.panel_rows, bn);
+  }
+
   // fused ResidualUnit (ru_fused.hip) for the 128-channel layers; `in` and `out` planes must differ
   bool ru_fusable(const ResUnit& r) const {
     static const bool off = getenv("DSN_NO_FUSED_RU") != nullptr;
@@ -742,6 +816,13 @@ struct dsn_ctx {
     op16_t* QKVp = wsbuf<op16_t>("dit_QKVp", M * 3 * D * P);
     op16_t* FF = wsbuf<op16_t>("dit_FF", M * 4 * D * P);
     float* SC = wsbuf<float>("sc", Mt * io);
+    // DSN_PREC_FP8: the layer GEMMs' A operands as e4m3 bytes + E8M0 block scales (LayerNorm output / attention
+    // output share one buffer, the SwiGLU hidden state has its own)
+    unsigned char* A8 = fp8 ? wsbuf<unsigned char>("dit_A8", M * D) : nullptr;
+    unsigned char* SA8 = fp8 ? wsbuf<unsigned char>("dit_SA8", M * D / 32) : nullptr;
+    unsigned char* H8 = fp8 ? wsbuf<unsigned char>("dit_H8", M * 4 * D) : nullptr;
+    unsigned char* SH8 = fp8 ? wsbuf<unsigned char>("dit_SH8", M * 4 * D / 32) : nullptr;
+    op16_t* lnout = fp8 ? reinterpret_cast<op16_t*>(A8) : Ap;
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
     const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
     float* rc = wsbuf<float>("rope_cos_" + std::to_string(S), (long)S * rot);
@@ -800,12 +881,12 @@ struct dsn_ctx {
       // algorithmic bytes of the fused reduce + LayerNorm: x in/out (when slabs are pending), slabs in, planes out
       auto ln_bytes = [&](int np) { return (double)M * D * (4.0 * (np ? 2 : 1) + 4.0 * np + 2.0 * P); };
       prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
-        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
-                             st);
+        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, lnout, M * D, PL, (int)M, D, 1e-5f,
+                             1, st, SA8);
       });
       {  // q|k|v operand planes: rotary + 1/sqrt(dh) fused into the epilogue
         Tag tg(this, "dit.qkv");
-        GemmDesc d = base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.qkv8, (int)M) : base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
         d.out_planes = QKVp;
         d.out_ps = M * 3 * D;
         d.rope_cos = rc;
@@ -818,18 +899,23 @@ struct dsn_ctx {
           const int np = cdiv(M, 272);
           d.panel_rows = short_panel ? panel_rows_for(cdiv(3 * D, qkv_panel)) : (cdiv(M, np) + 7) / 8 * 8;
         }
-        run(d, st, qkv_panel);
+        if (fp8) {
+          d.panel_rows = panel_rows_for(cdiv(3 * D, 256));
+          run_fp8(d, st, 256);
+        } else {
+          run(d, st, qkv_panel);
+        }
       }
       prof_launch("dit.attention", (double)M * D * 2.0 * P * 4.0, st,
-                  [&] { launch_attention_mfma(QKVp, M * 3 * D, Ap, M * D, PL, B, S, H, 64, st); });
+                  [&] { launch_attention_mfma(QKVp, M * 3 * D, lnout, M * D, PL, B, S, H, 64, st, SA8); });
       {
         Tag tg(this, "dit.attn_out");
-        GemmDesc d = base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.out8, (int)M) : base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
         static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
         int obn = 128, oks = 2;
         if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
-        d.ksplit = short_panel ? oks : pick_ksplit(d);
-        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks);
+        d.ksplit = (short_panel || fp8) ? oks : pick_ksplit(d);
+        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -839,21 +925,27 @@ struct dsn_ctx {
           d.resid = X;
           d.out_f32 = X;
         }
-        run(d, st, short_panel ? obn : 0);
+        if (fp8) run_fp8(d, st, obn);
+        else run(d, st, short_panel ? obn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
       }
       prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
-        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, Ap, M * D, PL, (int)M, D, 1e-5f, 1,
-                             st);
+        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, lnout, M * D, PL, (int)M, D, 1e-5f,
+                             1, st, SA8);
       });
       {
         // FF-in through the row-panel kernel: ceil(M/272) equal row panels x 256-column tiles -- for the
         // benchmark shape (M = 2112 -> 8 panels of 264 rows, N = 8192) exactly 256 workgroups, one round.
         Tag tg(this, "dit.ff_in");
-        GemmDesc d = base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.ff1_8, (int)M) : base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
         d.swiglu = 1;
-        d.out_planes = FF;
+        if (fp8) {
+          d.out_fp8 = H8;
+          d.out_fp8_scale = SH8;
+        } else {
+          d.out_planes = FF;
+        }
         d.out_ps = M * 4 * D;
         d.out_bstride = M * 4L * D;
         d.out_row_elems = 4 * D;
@@ -863,16 +955,21 @@ struct dsn_ctx {
           const int np = cdiv(M, 272);
           d.panel_rows = short_panel ? panel_rows_for(cdiv(4 * D * 2, 256)) : (cdiv(M, np) + 7) / 8 * 8;
         }
-        run(d, st, use_panel ? 256 : 0);
+        if (fp8) {
+          d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256));
+          run_fp8(d, st, 256);
+        } else {
+          run(d, st, use_panel ? 256 : 0);
+        }
       }
       {
         Tag tg(this, "dit.ff_out");
-        GemmDesc d = base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(H8, SH8, L.ff2_8, (int)M) : base_desc(FF, M * 4 * D, L.ff2, 1, (int)M, (int)M);
         static const char* fcfg = getenv("DSN_FF2_CFG");
         int fbn = 256, fks = 4;
         if (fcfg) sscanf(fcfg, "%d,%d", &fbn, &fks);
-        d.ksplit = short_panel ? fks : pick_ksplit(d);
-        if (short_panel) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks);
+        d.ksplit = (short_panel || fp8) ? fks : pick_ksplit(d);
+        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -884,7 +981,8 @@ struct dsn_ctx {
           d.out_f32 = X;
           pend_bias = nullptr;
         }
-        run(d, st, short_panel ? fbn : 0);
+        if (fp8) run_fp8(d, st, fbn);
+        else run(d, st, short_panel ? fbn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
       }
     }
@@ -1320,8 +1418,8 @@ extern "C" {
 dsn_ctx* dsn_create(const dsn_config* cfg) {
   try {
     if (!cfg) fail(DSN_EINVAL, "null config");
-    if (cfg->precision < DSN_PREC_BF16 || cfg->precision > DSN_PREC_FP16X3)
-      fail(DSN_EINVAL, "precision must be one of DSN_PREC_{BF16,BF16X3,FP16,FP16X3}");
+    if (cfg->precision < DSN_PREC_BF16 || cfg->precision > DSN_PREC_FP8)
+      fail(DSN_EINVAL, "precision must be one of DSN_PREC_{BF16,BF16X3,FP16,FP16X3,FP8}");
     if (cfg->vae_n_blocks < 0 || cfg->vae_n_blocks > DSN_MAX_VAE_BLOCKS) fail(DSN_EINVAL, "bad vae_n_blocks");
     if (cfg->n_src < 1 || cfg->latent_dim % 32 != 0) fail(DSN_EINVAL, "bad n_src / latent_dim");
     if (cfg->score_kind == DSN_SCORE_DIT &&
@@ -1337,6 +1435,9 @@ dsn_ctx* dsn_create(const dsn_config* cfg) {
     c->cfg = *cfg;
     c->P = (cfg->precision == DSN_PREC_BF16X3 || cfg->precision == DSN_PREC_FP16X3) ? 2 : 1;
     c->PL = DSN_PL(c->P, cfg->precision >= DSN_PREC_FP16 ? 1 : 0);
+    c->fp8 = cfg->precision == DSN_PREC_FP8;
+    if (c->fp8 && cfg->score_kind == DSN_SCORE_DIT && cfg->dit_embed_dim % 128 != 0)
+      fail(DSN_EINVAL, "DSN_PREC_FP8: embed_dim must be a multiple of 128 (got %d)", cfg->dit_embed_dim);
     return c;
   } catch (const std::exception& e) {
     g_create_err = e.what();

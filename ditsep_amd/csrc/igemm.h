@@ -63,6 +63,15 @@ struct GemmDesc {
   const float* rope_sin;
   int rope_S, qkv_D;
   float q_scale;
+  // fp8 (MX) operands, row-panel kernel only: A and W hold OCP e4m3 bytes (addressed as op16_t with every element
+  // count -- Cin, in_row_elems, strides -- given in PAIRS of bytes, i.e. K/2), a_scale [M][mx_kblocks] and
+  // w_scale [N][mx_kblocks] one E8M0 byte per 32 K-elements.  null = 16-bit operands.
+  const unsigned char* a_scale;
+  const unsigned char* w_scale;
+  int mx_kblocks;
+  // fp8 output of the SwiGLU epilogue (the next GEMM's A operand): e4m3 bytes [M][N/2] + E8M0 [M][N/64]
+  unsigned char* out_fp8;
+  unsigned char* out_fp8_scale;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
   int cfg_bm, cfg_bn, cfg_nst, cfg_bk;  // explicit tile configuration for igemm2_launch (0 = heuristic)
   int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)
@@ -76,6 +85,8 @@ hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nsta
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);
+// the same with fp8 (MX) operands: d.a_scale / d.w_scale set, d.Cin = K/2 (byte pairs), K % 128 == 0
+hipError_t igemm_panel_fp8_launch(const GemmDesc& d, int bn, hipStream_t stream);
 
 // Fused Oobleck ResidualUnit over 128-channel channels-last sequences (ru_fused.hip):
 //   out = X + conv1x1(act_mid(conv_k7_dil(A) + b7)) + b1 ;  planes(out) carry act_out for the consumer.

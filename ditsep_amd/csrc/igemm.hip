@@ -141,6 +141,37 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
           if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
         }
       }
+    } else if (d.out_fp8) {
+      // SwiGLU with fp8 (MX) output: the wave's 64 packed columns are 32 output features = ONE scale block of this
+      // row: amax over the lane's 8 values and the 4 lane groups that share the row, E8M0 scale, saturated e4m3
+      static_assert(NT == 4, "fp8 SwiGLU epilogue expects 64 packed columns per wave");
+      f32x4 h[2];
+      float amax = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const int np = nw0 + tp * 32;
+        f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
+        if (d.bias && np < d.N) {
+          val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
+          gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[tp][r] = val[r] * dsn_silu(gate[r]);
+          amax = fmaxf(amax, fabsf(h[tp][r]));
+        }
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int k = dsn_mx_exp(amax);
+      const float inv = dsn_pow2(-k);
+      if (nw0 < d.N) {
+        const long orow = (long)m * (d.N >> 1);
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+          *reinterpret_cast<unsigned*>(d.out_fp8 + orow + (nw0 >> 1) + tp * 16 + nq) = dsn_fp8x4(h[tp] * inv);
+        if ((lane >> 4) == 0) d.out_fp8_scale[(long)m * (d.N >> 6) + (nw0 >> 6)] = (unsigned char)(k + 127);
+      }
     } else {
       // SwiGLU: packed rows [32g, 32g+16) = value features 16g.., [32g+16, 32g+32) = their gates
 #pragma unroll
@@ -728,6 +759,156 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
   epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
 }
 
+
+// ============================================================================
+// fp8 (MX) twin of the row-panel kernel (DSN_PREC_FP8: the four DiT layer GEMMs).  Same geometry and ring; a
+// k-tile is 128 fp8 per row -- byte for byte the 64-element 16-bit tile -- consumed by ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator (twice the bf16 MFMA rate, half the staged bytes per K).
+// The E8M0 block scales (4 bytes per row per k-tile) ride through LDS too: every wave issues one 4-byte-per-lane
+// glds per k-tile for the scale dwords of 64 staged rows (waves beyond the staged rows load a zero page), so the
+// counted vmcnt stays uniform; lane (r, q) then reads byte q of its row's dword.
+// ============================================================================
+template <int WN_, int NST, int MT>
+__global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const GemmDesc d,
+                                                                             const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][A rows | W rows][64 pairs], then [NST][SROWS] u32
+  constexpr int TBK = 64;  // byte PAIRS per row per k-tile (128 fp8)
+  constexpr int NWAVES = 4 * WN_;
+  constexpr int MTW = (MT + 3) / 4;
+  constexpr int TBN = WN_ * 64;
+  constexpr int AROWS = MT * 16;
+  constexpr int ROWS = AROWS + TBN;
+  constexpr int STAGE_ELEMS = ROWS * TBK;
+  constexpr int CPR = TBK / 8;
+  constexpr int RPG = 64 / CPR;
+  constexpr int GROUPS = ROWS / RPG;
+  constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;
+  constexpr int REM = GROUPS % NWAVES;
+  constexpr int SG = (ROWS + 63) / 64;   // 64-row scale groups that hold staged rows: one per wave
+  constexpr int SROWS = (SG + 1) * 64;   // scale dwords per stage; waves >= SG land their (zero) load in the spare group
+  static_assert(SG <= NWAVES, "one scale group per wave must cover the staged rows");
+  unsigned* const slds = reinterpret_cast<unsigned*>(lds + NST * STAGE_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
+  constexpr int MBASE = MT / 4, MREM = MT % 4;
+  const int my_mt = MBASE + (wave_m < MREM ? 1 : 0);
+  const int my_row0 = 16 * (wave_m * MBASE + min(wave_m, MREM));
+  const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int ntiles = d.tiles_m * d.tiles_n;
+  const int z = t / ntiles;
+  const int tile = t - z * ntiles;
+  const int tile_m = d.m_fast ? tile % d.tiles_m : tile / d.tiles_n;
+  const int tile_n = d.m_fast ? tile / d.tiles_m : tile - tile_m * d.tiles_n;
+  const int m0 = tile_m * d.panel_rows, n0 = tile_n * TBN;
+  const int m_end = min(m0 + d.panel_rows, d.M);
+
+  const int Ktot = d.Cin;             // byte pairs per row (taps == 1)
+  const int nkt_all = d.Cin / TBK;
+  const int kt_begin = (int)((long)nkt_all * z / d.ksplit);
+  const int kt_end = (int)((long)nkt_all * (z + 1) / d.ksplit);
+  const int nkt = kt_end - kt_begin;
+
+  const int rsub = lane / CPR, cpos = lane % CPR;
+  RowLoad rl[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + gi * NWAVES;
+    const bool is_a = g < AROWS / RPG;
+    const int row = (is_a ? g : g - AROWS / RPG) * RPG + rsub;
+    const int gchunk = cpos ^ swzk<TBK>(row);
+    const int idx = (is_a ? m0 : n0) + row;
+    rl[gi] = make_row(d, is_a, idx, g < GROUPS && (is_a ? idx < m_end : idx < d.N), gchunk, Ktot);
+  }
+  const op16_t* zsrc = zero_page + cpos * 8;
+  // scale loader: rows wave*64 + lane of the staged panel
+  const int srow = wave * 64 + lane;
+  const bool s_is_a = srow < AROWS;
+  const int sidx = s_is_a ? m0 + srow : n0 + (srow - AROWS);
+  const bool s_ok = srow < ROWS && (s_is_a ? sidx < m_end : sidx < d.N);
+  const unsigned char* sptr = (s_is_a ? d.a_scale : d.w_scale) + (long)(s_ok ? sidx : 0) * d.mx_kblocks;
+  const unsigned char* szero = reinterpret_cast<const unsigned char*>(zero_page) + (lane & 31) * 4;
+  int kt_abs = kt_begin;
+
+  auto issue = [&](int stage) {
+    op16_t* sbase = lds + stage * STAGE_ELEMS;
+    const long off = (long)kt_abs * TBK;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      if (gi < my_groups) {
+        const int g = wave + gi * NWAVES;
+        const bool ok = rl[gi].mask & 1u;
+        const op16_t* gp = ok ? rl[gi].ptr + off : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(sbase + g * RPG * TBK), 16, 0, 0);
+      }
+    }
+    const unsigned char* sp = s_ok ? sptr + 4 * kt_abs : szero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                     (__attribute__((address_space(3))) void*)(slds + stage * SROWS + min(wave, SG) * 64), 4, 0,
+                                     0);
+    ++kt_abs;
+  };
+
+  f32x4 acc[4][MTW];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int fsw = swzk<TBK>(frow);
+  const int a_row_off = (my_row0 + frow) * TBK;
+  const int w_row_off = (AROWS + wave_n * 64 + frow) * TBK;
+  const int c_lo = (fchunk ^ fsw) * 8, c_hi = ((4 + fchunk) ^ fsw) * 8;
+
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2)
+    if (s2 < nkt) issue(s2);
+
+  for (int i = 0; i < nkt; ++i) {
+    const int younger = min(NST - 2, nkt - 1 - i);
+    if (NST >= 3 && younger >= 1) {
+      if (REM == 0 || wave < REM)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW + 1) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (i + NST - 1 < nkt) issue((i + NST - 1) % NST);
+
+    const op16_t* base = lds + (i % NST) * STAGE_ELEMS;
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(slds + (i % NST) * SROWS) + fchunk;
+    op16x8 fw0[4], fw1[4];
+    int sw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      fw0[k] = *reinterpret_cast<const op16x8*>(base + w_row_off + k * 16 * TBK + c_lo);
+      fw1[k] = *reinterpret_cast<const op16x8*>(base + w_row_off + k * 16 * TBK + c_hi);
+      sw[k] = sb[4 * (AROWS + wave_n * 64 + k * 16 + frow)];
+    }
+#pragma unroll
+    for (int tm = 0; tm < MTW; ++tm) {
+      if (tm < my_mt) {
+        const op16x8 fa0 = *reinterpret_cast<const op16x8*>(base + a_row_off + tm * 16 * TBK + c_lo);
+        const op16x8 fa1 = *reinterpret_cast<const op16x8*>(base + a_row_off + tm * 16 * TBK + c_hi);
+        const int sa = sb[4 * (my_row0 + tm * 16 + frow)];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tn][tm] = mfma_mx8(fw0[tn], fw1[tn], fa0, fa1, acc[tn][tm], sw[tn], sa);
+      }
+    }
+  }
+  epilogue_gen<1, 1, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
+}
+
 const op16_t* zero_page() {
   static op16_t* zp[64] = {};
   op16_t*& z = zp[dsn_current_device()];
@@ -841,6 +1022,43 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
   hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
                      zp);
   return hipGetLastError();
+}
+
+
+template <int WN_, int NST, int MT>
+static hipError_t launch_panel_fp8_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
+  constexpr int TBN = WN_ * 64;
+  d.tiles_m = cdiv(d.M, d.panel_rows);
+  d.tiles_n = cdiv(d.N, TBN);
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_fp8_kernel<WN_, NST, MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const int grid = d.tiles_m * d.tiles_n * d.ksplit;
+  const size_t smem = (size_t)NST * ((MT * 16 + TBN) * 64 * sizeof(op16_t) + ((MT * 16 + TBN + 63) / 64 + 1) * 64 * sizeof(unsigned));
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((igemm_panel_fp8_kernel<WN_, NST, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d, zp);
+  return hipGetLastError();
+}
+
+hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t stream) {
+  GemmDesc d = din;
+  if (d.ksplit < 1) d.ksplit = 1;
+  // plain row-major GEMM only: one "batch item" of M rows, one tap, K = 2 * Cin fp8 per row, whole 128-wide k-tiles
+  if (!d.a_scale || !d.w_scale || d.taps != 1 || d.in_stride != 1 || d.in_pad != 0 || d.rows_per_b != d.M ||
+      d.img_w > 0 || d.Cin % 64 != 0 || d.mx_kblocks != d.Cin / 16 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 ||
+      d.panel_rows > 17 * 16)
+    return hipErrorInvalidValue;
+  if (d.swiglu && (d.N % 64 != 0)) return hipErrorInvalidValue;
+  if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
+  const op16_t* zp = zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+#define FCFG(MT_, W_, NS_) \
+  if (d.panel_rows <= MT_ * 16 && bn == W_ * 64) return launch_panel_fp8_t<W_, NS_, MT_>(d, zp, stream);
+  FCFG(7, 4, 3) FCFG(9, 4, 3) FCFG(9, 2, 3) FCFG(13, 4, 2) FCFG(13, 2, 3) FCFG(17, 4, 2) FCFG(17, 2, 3)
+#undef FCFG
+  return hipErrorInvalidValue;
 }
 
 hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t stream) {

@@ -30,16 +30,19 @@ void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* s
 // ---- DiT pieces ---------------------------------------------------------------
 // x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a
 // plain copy to operand planes.  D <= 4096, D % 4 == 0.
+// out_fp8_scale != null: `out` receives fp8 (e4m3) bytes [rows][D] and out_fp8_scale E8M0 scales [rows][D/32].
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
-                          float eps, int do_norm, hipStream_t s);
+                          float eps, int do_norm, hipStream_t s, unsigned char* out_fp8_scale = nullptr);
 // FourierFeatures: t[B], w[half] -> planes [B][2*half] = [cos(2 pi t w), sin(2 pi t w)]
 void launch_timestep_features(const float* t, const float* w, int B, int half, op16_t* out, long ps,
                               int planes, hipStream_t s);
 // MFMA attention over operand planes q|k|v [B*S][3*H*64] written by the fused QKV epilogue
 // (attention.hip); S <= 256.
+// out_fp8_scale != null: `out` receives fp8 (e4m3) bytes [B*S][H*dh] and out_fp8_scale the E8M0 block scales
+// [B*S][H*dh/32] (MX operand of the fp8 out-projection) instead of 16-bit planes.
 int launch_attention_mfma(const op16_t* qkv, long ps, op16_t* out, long out_ps, int pl, int B, int S, int H, int dh,
-                          hipStream_t s);   // dh in {64,128,256}; returns -1 for an unsupported head width
+                          hipStream_t s, unsigned char* out_fp8_scale = nullptr);   // dh in {64,128,256}; -1: unsupported width
 void launch_rope_tables(float* cos_t, float* sin_t, int S, int rot, hipStream_t s);
 
 // ---- Oobleck edges -------------------------------------------------------------
@@ -67,6 +70,10 @@ void launch_wn_scale(const float* v, const float* g, float* scale, int R, long i
 void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long ps, int planes, int mode,
                         int N, int K, int Cin, int Cout, int kw, int stride, hipStream_t s);
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t s);
+// Linear weight [N][K] fp32 (swiglu: rows interleaved as PACK_LINEAR_SWIGLU) -> fp8 e4m3 bytes [N][K] + E8M0 block
+// scales [N][K/32] (one per 32 consecutive K-elements); K % 32 == 0
+void launch_pack_weight_fp8(const float* src, unsigned char* dst, unsigned char* scales, int N, int K, int swiglu,
+                            hipStream_t s);
 // snake parameters: alpha -> exp(alpha), beta -> 1/(exp(beta)+1e-9)
 void launch_snake_params(const float* alpha, const float* beta, float* a_out, float* ib_out, int C,
                          hipStream_t s);

@@ -185,7 +185,7 @@ __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restr
                                      long slab_stride, const float* __restrict__ bias,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      op16_t* __restrict__ out, long ps, int planes, int rows, int D, float eps,
-                                     int do_norm) {
+                                     int do_norm, unsigned char* __restrict__ o8s) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int nv = D >> 2;
@@ -238,6 +238,17 @@ __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restr
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * g[r];
           if (beta) o += reinterpret_cast<const f32x4*>(beta)[i];
+        }
+        if (o8s) {
+          // fp8 (MX) output: a 32-column scale block = the quads of 8 consecutive lanes (nv % 8 == 0: whole groups)
+          float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+          amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+          const int kx = dsn_mx_exp(amax);
+          reinterpret_cast<unsigned*>(out)[(rbase >> 2) + i] = dsn_fp8x4(o * dsn_pow2(-kx));
+          if ((lane & 7) == 0) o8s[(rbase >> 5) + (i >> 3)] = (unsigned char)(kx + 127);
+          continue;
         }
         op16x4 hi, lo;
 #pragma unroll
@@ -593,6 +604,36 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const float* _
   }
 }
 
+// one thread per (row, 32-element block): amax -> E8M0 scale -> 32 saturated e4m3 bytes
+__global__ void pack_weight_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                       unsigned char* __restrict__ scales, int N, int K, int swiglu) {
+  const int kb = K >> 5;
+  const long total = (long)N * kb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / kb), b = (int)(i - (long)n * kb);
+    int srow = n;
+    if (swiglu) {
+      const int F = N / 2, g = n >> 5, w = n & 31;
+      srow = w < 16 ? 16 * g + w : F + 16 * g + (w - 16);
+    }
+    const f32x4* sp = reinterpret_cast<const f32x4*>(src + (long)srow * K + b * 32);
+    f32x4 v[8];
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = sp[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(v[j][r]));
+    }
+    const int kx = dsn_mx_exp(amax);
+    const float inv = dsn_pow2(-kx);
+    unsigned* dp = reinterpret_cast<unsigned*>(dst + (long)n * K + b * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dp[j] = dsn_fp8x4(v[j] * inv);
+    scales[i] = (unsigned char)(kx + 127);
+  }
+}
+
 __global__ void pack_bias_swiglu_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
   const int F = N / 2;
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
@@ -651,10 +692,10 @@ void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, c
 }
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
-                          float eps, int do_norm, hipStream_t st) {
+                          float eps, int do_norm, hipStream_t st, unsigned char* o8s) {
 #define RN_LAUNCH(MV, NS_)                                                                                       \
   hipLaunchKernelGGL((residual_norm_kernel<MV, NS_>), dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab, \
-                     slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm)
+                     slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm, o8s)
 #define RN_SWITCH(MV)                                                                      \
   switch (nslab) {                                                                         \
     case 0: RN_LAUNCH(MV, 0); break;                                                       \
@@ -728,6 +769,11 @@ void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long 
                         int K, int Cin, int Cout, int kw, int stride, hipStream_t st) {
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)N * K)), dim3(TPB), 0, st, src, scale, dst, ps, planes,
                      mode, N, K, Cin, Cout, kw, stride);
+}
+void launch_pack_weight_fp8(const float* src, unsigned char* dst, unsigned char* scales, int N, int K, int swiglu,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3(grid_for((long)N * (K >> 5))), dim3(TPB), 0, st, src, dst, scales, N, K,
+                     swiglu);
 }
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t st) {
   hipLaunchKernelGGL(pack_bias_swiglu_kernel, dim3(grid_for(N)), dim3(TPB), 0, st, src, dst, N);

@@ -54,7 +54,7 @@ def _vae_arch(vae_cfg) -> dict:
 
 
 _PRECISIONS = {"bf16": native.PREC_BF16, "bf16x3": native.PREC_BF16X3, "fp16": native.PREC_FP16,
-               "fp16x3": native.PREC_FP16X3}
+               "fp16x3": native.PREC_FP16X3, "fp8": native.PREC_FP8}
 
 
 class LatentDiffSep:

@@ -19,6 +19,7 @@ PREC_BF16 = 1
 PREC_BF16X3 = 2
 PREC_FP16 = 3
 PREC_FP16X3 = 4
+PREC_FP8 = 5
 SCORE_NONE, SCORE_DIT, SCORE_NCSNPP = 0, 1, 2
 MAX_VAE_BLOCKS = 8
 

@@ -33,6 +33,10 @@ extern "C" {
 #define DSN_PREC_BF16X3 2  /* split-bf16 (hi,lo) operands: 3 bf16 MFMAs per product */
 #define DSN_PREC_FP16 3    /* fp16 MFMA operands (11-bit mantissa), fp32 accumulate */
 #define DSN_PREC_FP16X3 4  /* split-fp16 (hi,lo) operands: 3 fp16 MFMAs per product */
+#define DSN_PREC_FP8 5     /* BASELINE config 5: the DiT layer GEMMs (to_qkv, to_out, FF in/out) on fp8 e4m3 operands
+                              with E8M0 block scales per 32 K-elements (v_mfma_scale_f32_16x16x128_f8f6f4, fp32
+                              accumulate); everything else as DSN_PREC_FP16.  A throughput mode: e4m3 operand rounding
+                              (2^-4) cannot meet the 1e-3 waveform bound, its deviation is reported, not hidden. */
 
 #define DSN_SCORE_NONE 0
 #define DSN_SCORE_DIT 1    /* reference src/stable_audio_tools/models/dit.py:12-244  */

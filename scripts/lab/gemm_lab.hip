@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,10 @@ struct Prob {
   int M, N, K;
   int panel_rows, tiles_m, tiles_n;
   int m_fast;
+  const op16_t* Wnext;  // weights of the NEXT launch: touched (one dword per 128-B line) so they sit in the memory-side cache
+  long wnext_bytes;
+  int pf_mode;          // 0 off, 1 plain loads, 2 nontemporal loads
+  unsigned long long* stamps;  // [grid][4]: s_memtime / s_memrealtime at kernel start and end (wave 0)
 };
 
 template <int TBK>
@@ -81,6 +86,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void lab_kernel(const Prob d, const
   const int m_end = min(m0 + d.panel_rows, d.M);
   const int nkt = d.K / TBK;
 
+  unsigned long long t0c = 0, t0r = 0;
+  if (d.stamps && tid == 0) {
+    t0c = __builtin_amdgcn_s_memtime();
+    t0r = __builtin_amdgcn_s_memrealtime();
+  }
+  if (d.pf_mode) {  // prefetch this workgroup's slice of the next launch's weights
+    const long lines = d.wnext_bytes / 128;
+    const long per = (lines + gridDim.x - 1) / gridDim.x;
+    const long l0 = (long)blockIdx.x * per;
+    for (long l = l0 + tid; l < min(l0 + per, lines); l += blockDim.x) {
+      const unsigned* src = reinterpret_cast<const unsigned*>(d.Wnext) + l * 32;
+      unsigned v;
+      if (d.pf_mode == 2) v = __builtin_nontemporal_load(src);
+      else v = *reinterpret_cast<const volatile unsigned*>(src);
+      asm volatile("" ::"v"(v));
+    }
+  }
   const int rsub = lane / CPR, cpos = lane % CPR;
   const op16_t* rptr[GPW];
 #pragma unroll
@@ -128,23 +150,17 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void lab_kernel(const Prob d, const
     if (MODE == 2) {
       if (i == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else if (NST >= 3 && younger >= 1) {
-      // leave `younger` tiles in flight
-      if (younger == 1) {
-        if (REM == 0 || wave < REM)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW - 1) : "memory");
-      } else if (younger == 2) {
-        if (REM == 0 || wave < REM)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GPW) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (GPW - 1)) : "memory");
-      } else {
-        if (REM == 0 || wave < REM)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * GPW) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * (GPW - 1)) : "memory");
-      }
+      // leave `younger` tiles in flight (counted wait: younger x this wave's loads per tile)
+      const int mine = (REM == 0 || wave < REM) ? GPW : GPW - 1;
+#define WAITY(Y)                                                                                   \
+  if (younger == Y) {                                                                              \
+    if (mine == GPW)                                                                               \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((Y * GPW) > 63 ? 63 : (Y * GPW)) : "memory");        \
+    else                                                                                           \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((Y * (GPW - 1)) > 63 ? 63 : (Y * (GPW - 1))) : "memory"); \
+  }
+      WAITY(1) WAITY(2) WAITY(3) WAITY(4) WAITY(5) WAITY(6)
+#undef WAITY
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -168,6 +184,12 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void lab_kernel(const Prob d, const
         }
       }
     }
+  }
+  if (d.stamps && tid == 0) {
+    d.stamps[blockIdx.x * 4 + 0] = t0c;
+    d.stamps[blockIdx.x * 4 + 1] = t0r;
+    d.stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+    d.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }
   // epilogue: lane owns 4 consecutive channels (n) of row m = .. + (lane & 15)
   const int nq = (lane >> 4) * 4;
@@ -217,7 +239,10 @@ __global__ void fill_kernel(op16_t* p, long n, unsigned seed) {
 
 struct Bufs {
   op16_t *A, *C, *zero;
+  unsigned long long* stamps;
   std::vector<op16_t*> W;
+  int rot = 24;  // rotate over this many weight buffers (each launch uses the next one)
+  int pf = 0;
 };
 
 template <int WM, int WN, int MT, int NTW, int TBK, int NST, int MODE, int SWIGLU>
@@ -240,17 +265,22 @@ float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, in
   d.tiles_m = (M + panel_rows - 1) / panel_rows;
   d.tiles_n = (N + TBN - 1) / TBN;
   d.m_fast = 1;
+  d.pf_mode = b.pf;
+  d.stamps = b.stamps;
+  d.wnext_bytes = (long)N * K * 2;
   const int grid = d.tiles_m * d.tiles_n;
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   for (int w = 0; w < 3; ++w) {
-    d.W = b.W[w % b.W.size()];
+    d.W = b.W[w % b.rot];
+    d.Wnext = b.W[(w + 1) % b.rot];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, 0, d, b.zero);
   }
   CHK(hipEventRecord(e0, 0));
   for (int i = 0; i < iters; ++i) {
-    d.W = b.W[i % b.W.size()];
+    d.W = b.W[i % b.rot];
+    d.Wnext = b.W[(i + 1) % b.rot];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, 0, d, b.zero);
   }
   CHK(hipEventRecord(e1, 0));
@@ -259,10 +289,25 @@ float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, in
   float ms = 0;
   CHK(hipEventElapsedTime(&ms, e0, e1));
   const double us = 1e3 * ms / iters;
+  // main-loop clock and cycles of the last launch (median over workgroups)
+  std::vector<unsigned long long> st((size_t)grid * 4);
+  CHK(hipMemcpy(st.data(), b.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, ghz;
+  for (int g = 0; g < grid; ++g) {
+    const double dc = (double)(st[g * 4 + 2] - st[g * 4 + 0]), dr = (double)(st[g * 4 + 3] - st[g * 4 + 1]);
+    if (dr > 0) {
+      cyc.push_back(dc);
+      ghz.push_back(dc / dr * 0.1);
+    }
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(ghz.begin(), ghz.end());
+  const double mcyc = cyc.empty() ? 0 : cyc[cyc.size() / 2], mghz = ghz.empty() ? 0 : ghz[ghz.size() / 2];
   const double tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
   const double stage_gb = (double)grid * (MT * 16 + TBN) * K * 2.0 / 1e9;
-  printf("%-44s grid %4d wg %4d smem %6zu  %7.2f us  %6.0f TF  staged %.0f MB = %.1f GB/s/CU\n", name, grid, WM * WN * 64,
-         smem, us, MODE == 1 ? 0.0 : tf, stage_gb * 1e3, stage_gb / (us * 1e-6) / grid);
+  printf("%-44s pf %d rot %2d grid %4d wg %4d smem %6zu  %7.2f us  %6.0f TF  staged %.0f MB = %.1f GB/s/CU  loop %.0f cyc @ %.2f GHz\n",
+         name, b.pf, b.rot, grid, WM * WN * 64, smem, us, MODE == 1 ? 0.0 : tf, stage_gb * 1e3,
+         stage_gb / (us * 1e-6) / grid, mcyc, mghz);
   fflush(stdout);
   return (float)us;
 }
@@ -270,12 +315,14 @@ float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, in
 int main(int argc, char** argv) {
   const int M = 2112;
   const int iters = 48;
-  const int NW = 24;  // rotate over this many weight buffers
+  const int NW = 64;  // weight buffers (16.8 MB each: 1 GB)
   Bufs b;
   const long maxA = (long)M * 4096, maxW = 8192L * 1024, maxC = (long)M * 8192;
   CHK(hipMalloc((void**)&b.A, maxA * 2));
   CHK(hipMalloc((void**)&b.C, maxC * 2));
   CHK(hipMalloc((void**)&b.zero, 4096));
+  CHK(hipMalloc((void**)&b.stamps, 4096 * 4 * 8));
+  CHK(hipMemset(b.stamps, 0, 4096 * 4 * 8));
   CHK(hipMemset(b.zero, 0, 4096));
   fill_kernel<<<1024, 256>>>(b.A, maxA, 1);
   for (int i = 0; i < NW; ++i) {
@@ -291,36 +338,19 @@ int main(int argc, char** argv) {
 #define RUN(tag, WM, WN, MT, NTW, BK, NST, MODE, SW, M_, N_, K_, PR) \
   if (want(tag)) run_cfg<WM, WN, MT, NTW, BK, NST, MODE, SW>(tag, b, M_, N_, K_, PR, iters);
 
-  // ---- FF-in: N = 8192 (packed value|gate), K = 1024, 8 panels x 264 rows x 32 column tiles = 256 WGs
+  b.pf = 0;
+  b.rot = 64;
   RUN("ffin 16w 4x4 mt17 bk64 nst2 full", 4, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
   RUN("ffin 16w 4x4 mt17 bk64 nst2 stage-only", 4, 4, 17, 4, 64, 2, 1, 1, M, 8192, 1024, 264)
   RUN("ffin 16w 4x4 mt17 bk64 nst2 compute-only", 4, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
-  RUN("ffin 16w 4x4 mt17 bk32 nst4 full", 4, 4, 17, 4, 32, 4, 0, 1, M, 8192, 1024, 264)
-  RUN("ffin 16w 4x4 mt17 bk32 nst4 stage-only", 4, 4, 17, 4, 32, 4, 1, 1, M, 8192, 1024, 264)
-  RUN("ffin 16w 4x4 mt17 bk32 nst3 full", 4, 4, 17, 4, 32, 3, 0, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 2x4 mt17 bk64 nst2 full", 2, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
   RUN("ffin 8w 2x4 mt17 bk64 nst2 compute-only", 2, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 2x4 mt17 bk32 nst4 full", 2, 4, 17, 4, 32, 4, 0, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 2x4 mt17 bk32 nst4 stage-only", 2, 4, 17, 4, 32, 4, 1, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 2x4 mt17 bk32 nst4 compute-only", 2, 4, 17, 4, 32, 4, 2, 1, M, 8192, 1024, 264)
-  // ---- QKV: N = 3072, K = 1024, 21 panels x 104 rows x 12 column tiles = 252 WGs
+  RUN("ffin 8w 4x2 mt17 ntw8 bk64 nst2 compute-only", 4, 2, 17, 8, 64, 2, 2, 1, M, 8192, 1024, 264)
+  RUN("ffin 8w 4x2 mt17 ntw8 bk64 nst2 full", 4, 2, 17, 8, 64, 2, 0, 1, M, 8192, 1024, 264)
   RUN("qkv 16w 4x4 mt7 bk64 nst3 full", 4, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
-  RUN("qkv 16w 4x4 mt7 bk64 nst3 stage-only", 4, 4, 7, 4, 64, 3, 1, 0, M, 3072, 1024, 104)
   RUN("qkv 16w 4x4 mt7 bk64 nst3 compute-only", 4, 4, 7, 4, 64, 3, 2, 0, M, 3072, 1024, 104)
-  RUN("qkv 16w 4x4 mt7 bk64 nst4 full", 4, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
-  RUN("qkv 8w 2x4 mt7 bk64 nst4 full", 2, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
-  RUN("qkv 4w 1x4 mt7 bk64 nst4 full", 1, 4, 7, 4, 64, 4, 0, 0, M, 3072, 1024, 104)
-  // ---- out-proj without split-K: N = 1024, K = 1024: 32 panels x 66 rows x 8 column tiles(128) = 256 WGs
-  RUN("out 8w 2x4 mt5 ntw2 bk64 nst4 full (66x128)", 2, 4, 5, 2, 64, 4, 0, 0, M, 1024, 1024, 66)
-  RUN("out 4w 1x4 mt5 ntw2 bk64 nst4 full (66x128)", 1, 4, 5, 2, 64, 4, 0, 0, M, 1024, 1024, 66)
-  RUN("out 4w 1x4 mt5 ntw2 bk64 nst4 stage-only", 1, 4, 5, 2, 64, 4, 1, 0, M, 1024, 1024, 66)
-  RUN("out 4w 2x2 mt5 ntw4 bk64 nst4 full (66x128)", 2, 2, 5, 4, 64, 4, 0, 0, M, 1024, 1024, 66)
-  RUN("out 8w 2x4 mt9 ntw1 bk64 nst4 full (132x64)", 2, 4, 9, 1, 64, 4, 0, 0, M, 1024, 1024, 132)
-  // ---- FF-out without split-K: N = 1024, K = 4096
+  RUN("qkv 8w 2x4 mt7 bk64 nst3 full", 2, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
+  RUN("qkv 8w 2x4 mt7 bk64 nst3 compute-only", 2, 4, 7, 4, 64, 3, 2, 0, M, 3072, 1024, 104)
   RUN("ffout 8w 2x4 mt5 ntw2 bk64 nst4 full (66x128)", 2, 4, 5, 2, 64, 4, 0, 0, M, 1024, 4096, 66)
-  RUN("ffout 4w 1x4 mt5 ntw2 bk64 nst4 full (66x128)", 1, 4, 5, 2, 64, 4, 0, 0, M, 1024, 4096, 66)
-  RUN("ffout 4w 1x4 mt5 ntw2 bk64 nst4 stage-only", 1, 4, 5, 2, 64, 4, 1, 0, M, 1024, 4096, 66)
-  RUN("ffout 4w 2x2 mt5 ntw4 bk64 nst4 full (66x128)", 2, 2, 5, 4, 64, 4, 0, 0, M, 1024, 4096, 66)
-  RUN("ffout 4w 2x2 mt5 ntw4 bk128 nst3 full (66x128)", 2, 2, 5, 4, 128, 3, 0, 0, M, 1024, 4096, 66)
+  RUN("ffout 8w 2x4 mt5 ntw2 bk64 nst4 compute-only", 2, 4, 5, 2, 64, 4, 2, 0, M, 1024, 4096, 66)
   return 0;
 }
