@@ -163,6 +163,31 @@ def roofline_rows(prof, fp8_sites=()):
     return rows
 
 
+def measure_c5(engine, dcfg, dev, steps=2, batch=8):
+    """BASELINE config 5 shape on one GPU: 30 s mixtures at 16 kHz (T = 235 latent frames, 236 tokens), N = 30 +
+    1 corrector, hipGraph-captured sampler loop + plain decode; `batch` mixtures per step."""
+    import torch
+    from ditsep_amd import synthetic
+    L5 = 30 * FS
+    mix5 = synthetic.synthetic_sources(batch, dcfg.n_src, L5, FS, seed=4242).sum(1, keepdim=True).to(dev)
+    y5 = engine.encode(mix5, seed=11)
+
+    def step5(i):
+        x, _ = engine.pc_sample(y5, None, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS, seed=700 + i)
+        return engine.decode(x, L5)
+    for i in range(2):
+        step5(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step5(2 + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": round(batch * steps / el, 3), "unit": "utt/s (30 s mixtures)", "ms_per_step": round(1e3 * el / steps, 1),
+            "batch": batch, "latent_frames": int(y5.shape[-1]),
+            "workload": "C5 shape: 2-spk 16 kHz 30 s mixtures, N=30 PC sampler (60 NFE, hipGraph) + Oobleck decode"}
+
+
 def git_head():
     try:
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
@@ -384,6 +409,8 @@ def main():
             out["extra"] = {"c1_latency_ms_per_mixture": round(c1_ms, 2),
                             "c1": "config C1: 8 kHz x 4 s (T=16), N=10 + 1 corrector (20 NFE), batch 1, sampler + "
                                   "decode, hipGraph replay, mean of 10"}
+            if args.score == "dit":
+                out["extra"]["c5_long_form"] = measure_c5(eng, dcfg, dev)
         if not args.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
             cb, c2, c1 = cpu_baseline(dcfg, vcfg, dsd, vsd, y[:1], y1)
@@ -421,6 +448,8 @@ def main():
                        "rel_l2_waveform_vs_headline_mode": float((wb.double() - wa.double()).norm()
                                                                  / wa.double().norm())}
                 if name == "fp8":
+                    if not args.no_extra:
+                        rec["c5_long_form"] = measure_c5(eng2, dcfg, dev)
                     eng2.profile_begin()
                     step(20_000, eng2)
                     p2 = eng2.profile_end()
