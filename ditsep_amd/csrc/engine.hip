@@ -863,11 +863,11 @@ struct dsn_ctx {
     const bool short_panel = use_panel && !no_short && P == 1;  // split modes: measured, no gain
     // panel height for a GEMM with `wg_per_panel` = column tiles x split-K workgroups per row panel: as many
     // panels as fill whole rounds of 256 CUs
-    auto panel_rows_for = [&](int wg_per_panel) {
-      for (int rounds = 1;; ++rounds) {  // whole rounds of 256 workgroups, panels at most 272 rows tall
+    auto panel_rows_for = [&](int wg_per_panel, int max_rows = 272) {
+      for (int rounds = 1;; ++rounds) {  // whole rounds of 256 workgroups, panels at most max_rows (<= 272) rows tall
         const int np = std::max(1, 256 * rounds / std::max(1, wg_per_panel));
         const int rows = (cdiv(M, np) + 7) / 8 * 8;
-        if (rows <= 272) return rows;
+        if (rows <= max_rows) return rows;
       }
     };
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
@@ -900,7 +900,7 @@ struct dsn_ctx {
           d.panel_rows = short_panel ? panel_rows_for(cdiv(3 * D, qkv_panel)) : (cdiv(M, np) + 7) / 8 * 8;
         }
         if (fp8) {
-          d.panel_rows = panel_rows_for(cdiv(3 * D, 256));
+          d.panel_rows = panel_rows_for(cdiv(3 * D, 256), 208);
           run_fp8(d, st, 256);
         } else {
           run(d, st, qkv_panel);
@@ -915,7 +915,7 @@ struct dsn_ctx {
         int obn = 128, oks = 2;
         if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
         d.ksplit = (short_panel || fp8) ? oks : pick_ksplit(d);
-        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks);
+        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks, (fp8 && obn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;
@@ -956,7 +956,7 @@ struct dsn_ctx {
           d.panel_rows = short_panel ? panel_rows_for(cdiv(4 * D * 2, 256)) : (cdiv(M, np) + 7) / 8 * 8;
         }
         if (fp8) {
-          d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256));
+          d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256), 144);  // 256-column fp8 tiles: at most 9 row sub-tiles
           run_fp8(d, st, 256);
         } else {
           run(d, st, use_panel ? 256 : 0);
@@ -969,7 +969,7 @@ struct dsn_ctx {
         int fbn = 256, fks = 4;
         if (fcfg) sscanf(fcfg, "%d,%d", &fbn, &fks);
         d.ksplit = (short_panel || fp8) ? fks : pick_ksplit(d);
-        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks);
+        if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks, (fp8 && fbn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
           d.out_f32 = slabs;

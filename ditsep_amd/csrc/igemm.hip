@@ -768,13 +768,15 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
 // glds per k-tile for the scale dwords of 64 staged rows (waves beyond the staged rows load a zero page), so the
 // counted vmcnt stays uniform; lane (r, q) then reads byte q of its row's dword.
 // ============================================================================
-template <int WN_, int NST, int MT>
-__global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const GemmDesc d,
+template <int WM_, int WN_, int NST, int MT>
+__global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(const GemmDesc d,
                                                                              const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][A rows | W rows][64 pairs], then [NST][SROWS] u32
   constexpr int TBK = 64;  // byte PAIRS per row per k-tile (128 fp8)
-  constexpr int NWAVES = 4 * WN_;
-  constexpr int MTW = (MT + 3) / 4;
+  // WM_ x WN_ waves (8 for the tall panels: the 32-byte fp8 fragments need the 256-register budget of 2 waves per
+  // SIMD); the MT row sub-tiles are dealt over the WM_ wave rows
+  constexpr int NWAVES = WM_ * WN_;
+  constexpr int MTW = (MT + WM_ - 1) / WM_;
   constexpr int TBN = WN_ * 64;
   constexpr int AROWS = MT * 16;
   constexpr int ROWS = AROWS + TBN;
@@ -784,16 +786,16 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
   constexpr int GROUPS = ROWS / RPG;
   constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;
   constexpr int REM = GROUPS % NWAVES;
-  constexpr int SG = (ROWS + 63) / 64;   // 64-row scale groups that hold staged rows: one per wave
-  constexpr int SROWS = (SG + 1) * 64;   // scale dwords per stage; waves >= SG land their (zero) load in the spare group
-  static_assert(SG <= NWAVES, "one scale group per wave must cover the staged rows");
+  constexpr int SG = (ROWS + 63) / 64;             // 64-row scale groups that hold staged rows
+  constexpr int SGW = (SG + NWAVES - 1) / NWAVES;  // scale groups per wave (uniform: tail slots load a zero page)
+  constexpr int SROWS = (SG + 1) * 64;             // scale dwords per stage; slots >= SG land in the spare group
   unsigned* const slds = reinterpret_cast<unsigned*>(lds + NST * STAGE_ELEMS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
-  constexpr int MBASE = MT / 4, MREM = MT % 4;
+  constexpr int MBASE = MT / WM_, MREM = MT % WM_;
   const int my_mt = MBASE + (wave_m < MREM ? 1 : 0);
   const int my_row0 = 16 * (wave_m * MBASE + min(wave_m, MREM));
   const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
@@ -816,7 +818,8 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
   const int nkt = kt_end - kt_begin;
 
   const int rsub = lane / CPR, cpos = lane % CPR;
-  RowLoad rl[GPW];
+  const op16_t* zsrc = zero_page + cpos * 8;
+  const op16_t* rptr[GPW];  // this lane's 16-byte slot of each staged row at k = 0 (rows outside M / N: the zero page)
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave + gi * NWAVES;
@@ -824,16 +827,20 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
     const int row = (is_a ? g : g - AROWS / RPG) * RPG + rsub;
     const int gchunk = cpos ^ swzk<TBK>(row);
     const int idx = (is_a ? m0 : n0) + row;
-    rl[gi] = make_row(d, is_a, idx, g < GROUPS && (is_a ? idx < m_end : idx < d.N), gchunk, Ktot);
+    const bool ok = g < GROUPS && (is_a ? idx < m_end : idx < d.N);
+    rptr[gi] = ok ? (is_a ? d.A : d.W) + (long)idx * Ktot + gchunk * 8 : nullptr;
   }
-  const op16_t* zsrc = zero_page + cpos * 8;
-  // scale loader: rows wave*64 + lane of the staged panel
-  const int srow = wave * 64 + lane;
-  const bool s_is_a = srow < AROWS;
-  const int sidx = s_is_a ? m0 + srow : n0 + (srow - AROWS);
-  const bool s_ok = srow < ROWS && (s_is_a ? sidx < m_end : sidx < d.N);
-  const unsigned char* sptr = (s_is_a ? d.a_scale : d.w_scale) + (long)(s_ok ? sidx : 0) * d.mx_kblocks;
+  // scale loader: slot j of this wave = rows (wave + j*NWAVES)*64 + lane of the staged panel
   const unsigned char* szero = reinterpret_cast<const unsigned char*>(zero_page) + (lane & 31) * 4;
+  const unsigned char* sptr[SGW];
+#pragma unroll
+  for (int j = 0; j < SGW; ++j) {
+    const int srow = (wave + j * NWAVES) * 64 + lane;
+    const bool s_is_a = srow < AROWS;
+    const int sidx = s_is_a ? m0 + srow : n0 + (srow - AROWS);
+    const bool s_ok = srow < ROWS && (s_is_a ? sidx < m_end : sidx < d.N);
+    sptr[j] = s_ok ? (s_is_a ? d.a_scale : d.w_scale) + (long)sidx * d.mx_kblocks : nullptr;
+  }
   int kt_abs = kt_begin;
 
   auto issue = [&](int stage) {
@@ -843,16 +850,18 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
     for (int gi = 0; gi < GPW; ++gi) {
       if (gi < my_groups) {
         const int g = wave + gi * NWAVES;
-        const bool ok = rl[gi].mask & 1u;
-        const op16_t* gp = ok ? rl[gi].ptr + off : zsrc;
+        const op16_t* gp = rptr[gi] ? rptr[gi] + off : zsrc;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                          (__attribute__((address_space(3))) void*)(sbase + g * RPG * TBK), 16, 0, 0);
       }
     }
-    const unsigned char* sp = s_ok ? sptr + 4 * kt_abs : szero;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                     (__attribute__((address_space(3))) void*)(slds + stage * SROWS + min(wave, SG) * 64), 4, 0,
-                                     0);
+#pragma unroll
+    for (int j = 0; j < SGW; ++j) {
+      const unsigned char* sp = sptr[j] ? sptr[j] + 4 * kt_abs : szero;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)sp,
+          (__attribute__((address_space(3))) void*)(slds + stage * SROWS + min(wave + j * NWAVES, SG) * 64), 4, 0, 0);
+    }
     ++kt_abs;
   };
 
@@ -876,9 +885,9 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
     const int younger = min(NST - 2, nkt - 1 - i);
     if (NST >= 3 && younger >= 1) {
       if (REM == 0 || wave < REM)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW + 1) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW + SGW) : "memory");
       else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW - 1 + SGW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -895,15 +904,28 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_fp8_kernel(const 
       fw1[k] = *reinterpret_cast<const op16x8*>(base + w_row_off + k * 16 * TBK + c_hi);
       sw[k] = sb[4 * (AROWS + wave_n * 64 + k * 16 + frow)];
     }
+    // activation fragments one row sub-tile ahead of the MFMAs that use them; the scheduling fence per sub-tile keeps
+    // hipcc from hoisting every fragment read to the top (9 x 8 registers: spills at MT = 17)
+    op16x8 fa0 = *reinterpret_cast<const op16x8*>(base + a_row_off + c_lo);
+    op16x8 fa1 = *reinterpret_cast<const op16x8*>(base + a_row_off + c_hi);
+    int sa = sb[4 * (my_row0 + frow)];
 #pragma unroll
     for (int tm = 0; tm < MTW; ++tm) {
+      op16x8 na0 = fa0, na1 = fa1;
+      int nsa = sa;
+      if (tm + 1 < MTW) {
+        na0 = *reinterpret_cast<const op16x8*>(base + a_row_off + (tm + 1) * 16 * TBK + c_lo);
+        na1 = *reinterpret_cast<const op16x8*>(base + a_row_off + (tm + 1) * 16 * TBK + c_hi);
+        nsa = sb[4 * (my_row0 + (tm + 1) * 16 + frow)];
+      }
       if (tm < my_mt) {
-        const op16x8 fa0 = *reinterpret_cast<const op16x8*>(base + a_row_off + tm * 16 * TBK + c_lo);
-        const op16x8 fa1 = *reinterpret_cast<const op16x8*>(base + a_row_off + tm * 16 * TBK + c_hi);
-        const int sa = sb[4 * (my_row0 + tm * 16 + frow)];
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tn][tm] = mfma_mx8(fw0[tn], fw1[tn], fa0, fa1, acc[tn][tm], sw[tn], sa);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      fa0 = na0;
+      fa1 = na1;
+      sa = nsa;
     }
   }
   epilogue_gen<1, 1, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
@@ -1025,20 +1047,20 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
 }
 
 
-template <int WN_, int NST, int MT>
+template <int WM_, int WN_, int NST, int MT>
 static hipError_t launch_panel_fp8_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_fp8_kernel<WN_, NST, MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_fp8_kernel<WM_, WN_, NST, MT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * ((MT * 16 + TBN) * 64 * sizeof(op16_t) + ((MT * 16 + TBN + 63) / 64 + 1) * 64 * sizeof(unsigned));
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((igemm_panel_fp8_kernel<WN_, NST, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d, zp);
+  hipLaunchKernelGGL((igemm_panel_fp8_kernel<WM_, WN_, NST, MT>), dim3(grid), dim3(WM_ * WN_ * 64), smem, stream, d, zp);
   return hipGetLastError();
 }
 
@@ -1054,9 +1076,11 @@ hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t strea
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define FCFG(MT_, W_, NS_) \
-  if (d.panel_rows <= MT_ * 16 && bn == W_ * 64) return launch_panel_fp8_t<W_, NS_, MT_>(d, zp, stream);
-  FCFG(7, 4, 3) FCFG(9, 4, 3) FCFG(9, 2, 3) FCFG(13, 4, 2) FCFG(13, 2, 3) FCFG(17, 4, 2) FCFG(17, 2, 3)
+#define FCFG(MT_, WM_, W_, NS_) \
+  if (d.panel_rows <= MT_ * 16 && bn == W_ * 64) return launch_panel_fp8_t<WM_, W_, NS_, MT_>(d, zp, stream);
+  // 16 waves only where the accumulators leave room under the 128-register cap; tall panels run 8 waves (a 272-row
+  // x 256-column tile does not fit 256 registers per lane with 32-byte fragments: callers use <= 208 rows there)
+  FCFG(7, 4, 4, 3) FCFG(9, 2, 4, 3) FCFG(9, 4, 2, 3) FCFG(13, 2, 4, 2) FCFG(13, 4, 2, 3) FCFG(17, 4, 2, 3)
 #undef FCFG
   return hipErrorInvalidValue;
 }
