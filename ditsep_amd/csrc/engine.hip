@@ -77,6 +77,9 @@ struct DitLayer {
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
   Packed qkv, out, ff1, ff2;
   Packed8 qkv8, out8, ff1_8, ff2_8;  // DSN_PREC_FP8
+  // ff_norm folded into FF-in (single-plane modes): W * diag(gamma) packed, its rounded row sums, bias + W beta
+  Packed ff1f;
+  float* ff1_colsum = nullptr;
 };
 
 struct ResUnit {
@@ -121,6 +124,7 @@ struct dsn_ctx {
   int P = 2;   // operand planes
   int PL = 2;  // DSN_PL(P, fp16 flag) as the kernels take it
   bool fp8 = false;  // DSN_PREC_FP8: DiT layer GEMMs on fp8 (MX) operands, the rest single-plane fp16
+  bool fold_ln = false;  // ff_norm folded into FF-in, to_out without split-K writing the residual stream itself
   bool finalized = false;
   bool use_graphs = false;
   double hbm_ms = 0, hbm_bytes = 0;  // HBM-bound launches of the last profiled region (dsn_profile_hbm)
@@ -495,6 +499,7 @@ struct dsn_ctx {
       ++ws_epoch;
     }
     const int D = cfg.dit_embed_dim;
+    fold_ln = P == 1 && !fp8 && D % 64 == 0 && getenv("DSN_NO_LN_FOLD") == nullptr;
     if (cfg.score_kind == DSN_SCORE_DIT) {
       const std::string sp = "score_model.";
       if (D % 64 != 0 || cfg.dit_heads <= 0 || D / cfg.dit_heads != 64 || D % cfg.dit_heads != 0)
@@ -524,6 +529,29 @@ struct dsn_ctx {
         L.out = pack_linear(lp + "self_attn.to_out.weight", "", false, st);
         L.ff1 = pack_linear(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
         L.ff2 = pack_linear(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
+        if (fold_ln) {
+          // LN(x) W^T = rstd (x (W diag(gamma))^T - mean colsum) + (b + W beta): gamma into the packed weight, the
+          // row sums from the ROUNDED packed values, beta into the bias (dit_forward: FF-in consumes raw x planes)
+          const DevTensor& w = get(lp + "ff.ff.0.proj.weight");
+          Packed& p = L.ff1f;
+          p.N = (int)w.shape[0];
+          p.K = p.Cin = (int)(w.numel / w.shape[0]);
+          p.taps = 1;
+          p.ps = (long)p.N * p.K;
+          p.w = (op16_t*)dmalloc(sizeof(op16_t) * p.ps * P);
+          launch_pack_weight(w.p, nullptr, p.w, p.ps, PL, PACK_LINEAR_SWIGLU, p.N, p.K, p.K, p.N, 1, 1, st, L.g2);
+          L.ff1_colsum = (float*)dmalloc(sizeof(float) * p.N);
+          launch_packed_row_sum(p.w, p.ps, PL, p.N, p.K, L.ff1_colsum, st);
+          const float* b1 = maybe(lp + "ff.ff.0.proj.bias");
+          p.bias = L.ff1.bias;
+          if (L.be2) {
+            float* tmp = (float*)dmalloc(sizeof(float) * p.N);
+            launch_bias_plus_wbeta(w.p, L.be2, b1, p.N, p.K, tmp, st);
+            p.bias = (float*)dmalloc(sizeof(float) * p.N);
+            launch_pack_bias_swiglu(tmp, p.bias, p.N, st);
+          }
+          p.bias_mod = p.N;
+        }
       }
     }
     if (cfg.score_kind == DSN_SCORE_NCSNPP) finalize_ncsnpp(st);
@@ -806,6 +834,7 @@ struct dsn_ctx {
     }
   } time_cache;
 
+  static bool use_panel_ok(int D) { return getenv("DSN_NO_PANEL") == nullptr && D % 64 == 0; }
   float* dit_forward(const float* xt, const float* t, const float* mix, int B, int T, hipStream_t st) {
     const int n = cfg.n_src, Dl = cfg.latent_dim, D = cfg.dit_embed_dim, H = cfg.dit_heads;
     const int io = n * Dl, din = io + Dl, S = T + 1;
@@ -823,6 +852,18 @@ struct dsn_ctx {
     unsigned char* H8 = fp8 ? wsbuf<unsigned char>("dit_H8", M * 4 * D) : nullptr;
     unsigned char* SH8 = fp8 ? wsbuf<unsigned char>("dit_SH8", M * 4 * D / 32) : nullptr;
     op16_t* lnout = fp8 ? reinterpret_cast<op16_t*>(A8) : Ap;
+    // folded ff_norm (single-plane modes, panels of at most 80 rows fill whole rounds): to_out runs WITHOUT split-K in
+    // 128-column tiles, adds the residual itself and writes x' (fp32), its raw operand plane and per-row statistics;
+    // FF-in then applies the LayerNorm algebraically in its epilogue -- the LayerNorm launch between them is gone
+    int fold_rows = 0;
+    if (fold_ln && use_panel_ok(D)) {
+      for (int rounds = 1; rounds <= 4 && !fold_rows; ++rounds) {
+        const int np = 256 * rounds / std::max(1, cdiv(D, 128));
+        if (np >= 1 && cdiv(M, np) <= 80) fold_rows = cdiv(M, np);
+      }
+    }
+    op16_t* Xp = fold_rows ? wsbuf<op16_t>("dit_Xp", M * D) : nullptr;
+    float* ST = fold_rows ? wsbuf<float>("dit_ST", M * (D / 64) * 2) : nullptr;
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
     const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
     float* rc = wsbuf<float>("rope_cos_" + std::to_string(S), (long)S * rot);
@@ -911,6 +952,19 @@ struct dsn_ctx {
       {
         Tag tg(this, "dit.attn_out");
         GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.out8, (int)M) : base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
+        if (fold_rows) {
+          d.panel_rows = fold_rows;
+          d.resid = X;
+          d.out_f32 = X;
+          d.out_planes = Xp;
+          d.out_ps = M * D;
+          d.stat_out = ST;
+          d.stat_np = D / 64;
+          d.m_fast = 1;
+          run(d, st, 128);
+          pend_n = 0;
+          pend_bias = nullptr;
+        } else {
         static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
         int obn = 128, oks = 2;
         if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
@@ -929,17 +983,27 @@ struct dsn_ctx {
         else run(d, st, short_panel ? obn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
+        }
       }
-      prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
-        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, lnout, M * D, PL, (int)M, D, 1e-5f,
-                             1, st, SA8);
-      });
+      if (!fold_rows)
+        prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
+          launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g2, L.be2, lnout, M * D, PL, (int)M, D,
+                               1e-5f, 1, st, SA8);
+        });
       {
         // FF-in through the row-panel kernel: ceil(M/272) equal row panels x 256-column tiles -- for the
         // benchmark shape (M = 2112 -> 8 panels of 264 rows, N = 8192) exactly 256 workgroups, one round.
         Tag tg(this, "dit.ff_in");
-        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.ff1_8, (int)M) : base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.ff1_8, (int)M)
+                         : (fold_rows ? base_desc(Xp, M * D, L.ff1f, 1, (int)M, (int)M)
+                                      : base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M));
         d.swiglu = 1;
+        if (fold_rows) {
+          d.ln_stats = ST;
+          d.ln_np = D / 64;
+          d.ln_colsum = L.ff1_colsum;
+          d.ln_eps = 1e-5f;
+        }
         if (fp8) {
           d.out_fp8 = H8;
           d.out_fp8_scale = SH8;

@@ -72,6 +72,20 @@ struct GemmDesc {
   // fp8 output of the SwiGLU epilogue (the next GEMM's A operand): e4m3 bytes [M][N/2] + E8M0 [M][N/64]
   unsigned char* out_fp8;
   unsigned char* out_fp8_scale;
+  // LayerNorm folded into the consuming GEMM (row-panel kernel, single-plane modes).
+  // Producer side (a GEMM whose fp32 output is the residual stream x'): stat_out [M][stat_np][2] receives, per row and
+  // per 64-column wave slice, (mean, sum of squared deviations from that mean) of x' -- exact two-pass values from the
+  // accumulator registers; N % 64 == 0, stat_np = N / 64.
+  float* stat_out;
+  int stat_np;
+  // Consumer side: A holds the RAW x' operand plane, W = W_orig * diag(gamma); the epilogue applies
+  //   LN(x') W_orig^T = rstd * (x' W^T - mean * colsum) (+ bias, which already carries beta W_orig^T)
+  // with (mean, rstd) per row combined from ln_stats [M][ln_np][2] (Chan's parallel formula, fixed order) into LDS by
+  // the kernel prologue, and colsum[n] = sum_k W[n][k] of the ROUNDED packed weights.  null = off.
+  const float* ln_stats;
+  int ln_np;
+  const float* ln_colsum;
+  float ln_eps;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
   int cfg_bm, cfg_bn, cfg_nst, cfg_bk;  // explicit tile configuration for igemm2_launch (0 = heuristic)
   int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)

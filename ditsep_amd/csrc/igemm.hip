@@ -34,9 +34,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row 
 
 // Generic epilogue of one wave: NT column sub-tiles x MT row sub-tiles of 16x16 accumulators starting
 // at (row mw0, column nw0); rows at or beyond m_end are not stored.
+// ln_rows (LDS, folded-LayerNorm consumers): (mean, rstd) of panel row i at ln_rows[2 * i], i = m - ln_m0.
 template <int P, int F16, int NT, int MT>
 __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
-                                             int lane, int z) {
+                                             int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
   const int nq = (lane >> 4) * 4;
   if (d.ksplit > 1) {  // raw partial sums to this slice's slab
     float* slab = d.out_f32 + (long)z * d.slab_stride;
@@ -140,6 +141,28 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
           *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
           if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
         }
+        if (d.stat_out) acc[tn][tm] = v;  // keep x' for the row statistics below
+      }
+      if (d.stat_out) {
+        // (mean, M2) of this row's 64 columns held by the wave: 16 values per lane x the 4 lane groups of the row
+        float s1 = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) s1 += (acc[tn][tm][0] + acc[tn][tm][1]) + (acc[tn][tm][2] + acc[tn][tm][3]);
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.f / (NT * 16));
+        float m2 = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dl = acc[tn][tm][r] - mean;
+            m2 += dl * dl;
+          }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if ((lane >> 4) == 0)
+          *reinterpret_cast<float2*>(d.stat_out + ((long)m * d.stat_np + nw0 / (NT * 16)) * 2) = float2{mean, m2};
       }
     } else if (d.out_fp8) {
       // SwiGLU with fp8 (MX) output: the wave's 64 packed columns are 32 output features = ONE scale block of this
@@ -181,6 +204,13 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         const int feat = (np >> 1) + nq;
         const long off = row_abs + feat;
         f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
+        if (ln_rows) {  // folded LayerNorm: rstd * (x' W^T - mean * colsum)
+          const float mu = ln_rows[2 * (m - ln_m0)], rs = ln_rows[2 * (m - ln_m0) + 1];
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + nq);
+          const f32x4 cg = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + 16 + nq);
+          val = (val - cv * mu) * rs;
+          gate = (gate - cg * mu) * rs;
+        }
         if (d.bias) {
           val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
           gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
@@ -713,9 +743,34 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
   for (int s2 = 0; s2 < NST - 1; ++s2)
     if (s2 < nkt) issue(s2);
 
+  // folded LayerNorm: (mean, rstd) of this panel's rows from the producer's per-slice partials, combined in slice
+  // order (Chan's parallel formula) -> LDS behind the ring; the first k-tile's barrier publishes them long before
+  // the epilogue reads them
+  float* const ln_rows = reinterpret_cast<float*>(lds + NST * STAGE_ELEMS);
+  if (d.ln_stats) {
+    for (int r = tid; r < m_end - m0; r += NWAVES * 64) {
+      const float2* ps = reinterpret_cast<const float2*>(d.ln_stats) + (long)(m0 + r) * d.ln_np;
+      float msum = 0.f, m2 = 0.f;
+      for (int p2 = 0; p2 < d.ln_np; ++p2) msum += ps[p2].x;
+      const float mean = msum / (float)d.ln_np;
+      const float cnt = (float)(d.Cin * d.taps) / (float)d.ln_np;  // columns per slice
+      for (int p2 = 0; p2 < d.ln_np; ++p2) {
+        const float dm = ps[p2].x - mean;
+        m2 += ps[p2].y + cnt * dm * dm;
+      }
+      ln_rows[2 * r] = mean;
+      ln_rows[2 * r + 1] = rsqrtf(m2 / (float)(d.Cin * d.taps) + d.ln_eps);
+    }
+  }
+
   for (int i = 0; i < nkt; ++i) {
     const int younger = min(NST - 2, nkt - 1 - i);
-    if (NST >= 3 && younger >= 1) {
+    if (NST >= 4 && younger >= 2) {  // two younger tiles stay in flight
+      if (REM == 0 || wave < REM)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GPW * P) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (GPW - 1) * P) : "memory");
+    } else if (NST >= 3 && younger >= 1) {
       if (REM == 0 || wave < REM)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GPW * P) : "memory");
       else
@@ -756,7 +811,8 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
     }
   }
   // rows m0 + my_row0 + tm*16 ...; wave rows 1..3 never touch their (unused) 5th sub-tile: mask it by row
-  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
+  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z,
+                               d.ln_stats ? ln_rows : nullptr, m0);
 }
 
 
@@ -1040,7 +1096,8 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t);
+  const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t) + (d.ln_stats ? MT * 16 * 2 * sizeof(float) : 0);
+  if (smem > 160 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
                      zp);
   return hipGetLastError();
@@ -1093,6 +1150,8 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   if (d.img_w > 0) return hipErrorInvalidValue;
+  if (d.stat_out && (d.N % 64 != 0 || d.stat_np != d.N / 64 || d.swiglu || d.ksplit > 1)) return hipErrorInvalidValue;
+  if (d.ln_stats && (!d.swiglu || !d.ln_colsum || d.ln_np <= 0 || d.taps != 1 || planes != 1)) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
 #define PCFG(P_, W_, NS_, BK_)                                                                   \
@@ -1101,6 +1160,9 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
 #define PCFGS(MT_, P_, W_, NS_, BK_)                                                  \
   if (planes == P_ && bn == W_ * 64)                                                  \
     return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, MT_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_, MT_>(d, zp, stream);
+  if (d.panel_rows <= 5 * 16) {  // 66-row panels x 128 columns: the N = D residual-stream GEMMs without split-K
+    PCFGS(5, 1, 2, 4, 64)
+  }
   if (d.panel_rows <= 7 * 16) {  // 112-row panels (single-plane modes)
     PCFGS(7, 1, 4, 3, 64)
   }

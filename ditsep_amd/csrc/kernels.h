@@ -67,8 +67,16 @@ enum { PACK_LINEAR = 0, PACK_LINEAR_SWIGLU = 1, PACK_CONV = 2, PACK_CONVT = 3, P
 // per-row scale g / ||v|| for old-style weight norm (norm over all dims but 0); v [R][inner]
 void launch_wn_scale(const float* v, const float* g, float* scale, int R, long inner, hipStream_t s);
 // generic gather into packed [N][K] planes; see kernels.hip for the index maps
+// colscale (PACK_LINEAR / PACK_LINEAR_SWIGLU only): per input column factor, W[n][k] * colscale[k] (LayerNorm gamma
+// folded into the consuming Linear)
 void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long ps, int planes, int mode,
-                        int N, int K, int Cin, int Cout, int kw, int stride, hipStream_t s);
+                        int N, int K, int Cin, int Cout, int kw, int stride, hipStream_t s,
+                        const float* colscale = nullptr);
+// out[n] = sum_k packed[n][k] (the rounded operand values; both planes in the split modes)
+void launch_packed_row_sum(const op16_t* w, long ps, int planes, int N, int K, float* out, hipStream_t s);
+// out[n] = (bias ? bias[n] : 0) + sum_k W[n][k] beta[k]
+void launch_bias_plus_wbeta(const float* W, const float* beta, const float* bias, int N, int K, float* out,
+                            hipStream_t s);
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t s);
 // Linear weight [N][K] fp32 (swiglu: rows interleaved as PACK_LINEAR_SWIGLU) -> fp8 e4m3 bytes [N][K] + E8M0 block
 // scales [N][K/32] (one per 32 consecutive K-elements); K % 32 == 0

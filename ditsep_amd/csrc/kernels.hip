@@ -573,17 +573,19 @@ __global__ void wn_scale_kernel(const float* __restrict__ v, const float* __rest
 
 __global__ void pack_weight_kernel(const float* __restrict__ src, const float* __restrict__ scale,
                                    op16_t* __restrict__ dst, long ps, int planes, int mode, int N, int K,
-                                   int Cin, int Cout, int kw, int stride) {
+                                   int Cin, int Cout, int kw, int stride, const float* __restrict__ colscale) {
   const long total = (long)N * K;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int n = (int)(i / K), k = (int)(i - (long)n * K);
     float v;
     if (mode == PACK_LINEAR) {
       v = src[(long)n * K + k];
+      if (colscale) v *= colscale[k];
     } else if (mode == PACK_LINEAR_SWIGLU) {
       const int F = N / 2, g = n >> 5, w = n & 31;
       const int srow = w < 16 ? 16 * g + w : F + 16 * g + (w - 16);
       v = src[(long)srow * K + k];
+      if (colscale) v *= colscale[k];
     } else if (mode == PACK_CONV) {
       const int tap = k / Cin, ci = k - tap * Cin;
       v = src[((long)n * Cin + ci) * kw + tap];
@@ -632,6 +634,33 @@ __global__ void pack_weight_fp8_kernel(const float* __restrict__ src, unsigned c
     for (int j = 0; j < 8; ++j) dp[j] = dsn_fp8x4(v[j] * inv);
     scales[i] = (unsigned char)(kx + 127);
   }
+}
+
+// colsum[n] = sum_k of the ROUNDED packed operand (plane 0 [+ plane 1]) of row n: the term the folded LayerNorm
+// subtracts (mean * colsum) must cancel against exactly the weights the MFMAs multiply.  One wave per row.
+__global__ void packed_row_sum_kernel(const op16_t* __restrict__ w, long ps, int planes, int N, int K,
+                                      float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63, f16 = PL_F16(planes);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    s += from_op16(w[(long)row * K + k], f16);
+    if (PL_COUNT(planes) == 2) s += from_op16(w[ps + (long)row * K + k], f16);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+// out[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]   (original row order).  One wave per row.
+__global__ void bias_plus_wbeta_kernel(const float* __restrict__ W, const float* __restrict__ beta,
+                                       const float* __restrict__ bias, int N, int K, float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += W[(long)row * K + k] * beta[k];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s + (bias ? bias[row] : 0.f);
 }
 
 __global__ void pack_bias_swiglu_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
@@ -766,9 +795,16 @@ void launch_wn_scale(const float* v, const float* g, float* scale, int R, long i
   hipLaunchKernelGGL(wn_scale_kernel, dim3(cdiv(R, 4)), dim3(TPB), 0, st, v, g, scale, R, inner);
 }
 void launch_pack_weight(const float* src, const float* scale, op16_t* dst, long ps, int planes, int mode, int N,
-                        int K, int Cin, int Cout, int kw, int stride, hipStream_t st) {
+                        int K, int Cin, int Cout, int kw, int stride, hipStream_t st, const float* colscale) {
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)N * K)), dim3(TPB), 0, st, src, scale, dst, ps, planes,
-                     mode, N, K, Cin, Cout, kw, stride);
+                     mode, N, K, Cin, Cout, kw, stride, colscale);
+}
+void launch_packed_row_sum(const op16_t* w, long ps, int planes, int N, int K, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(packed_row_sum_kernel, dim3(cdiv(N, 4)), dim3(TPB), 0, st, w, ps, planes, N, K, out);
+}
+void launch_bias_plus_wbeta(const float* W, const float* beta, const float* bias, int N, int K, float* out,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(bias_plus_wbeta_kernel, dim3(cdiv(N, 4)), dim3(TPB), 0, st, W, beta, bias, N, K, out);
 }
 void launch_pack_weight_fp8(const float* src, unsigned char* dst, unsigned char* scales, int N, int K, int swiglu,
                             hipStream_t st) {
