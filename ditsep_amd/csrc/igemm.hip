@@ -35,7 +35,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row 
 // Generic epilogue of one wave: NT column sub-tiles x MT row sub-tiles of 16x16 accumulators starting
 // at (row mw0, column nw0); rows at or beyond m_end are not stored.
 // ln_rows (LDS, folded-LayerNorm consumers): (mean, rstd) of panel row i at ln_rows[2 * i], i = m - ln_m0.
-template <int P, int F16, int NT, int MT>
+// EPI: compile-time feature bits, so that a kernel only carries (and allocates registers for) the epilogue code it can
+// run: 1 = row statistics of the output (d.stat_out), 2 = folded-LayerNorm consumer (ln_rows), 4 = fp8 SwiGLU output.
+enum { EPI_STATS = 1, EPI_LNFOLD = 2, EPI_FP8OUT = 4 };
+template <int P, int F16, int NT, int MT, int EPI = 0>
 __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
                                              int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
   const int nq = (lane >> 4) * 4;
@@ -56,6 +59,99 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         const long rel = row_rel + n;
         if (rel < 0 || rel >= d.out_limit) continue;
         *reinterpret_cast<f32x4*>(slab + row_abs + n) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+  if constexpr ((EPI & EPI_STATS) != 0) {
+    // Residual-stream producer (to_out without split-K): x' = acc + bias + x, written in place as fp32, as the raw
+    // operand plane, and summarised per row (mean, M2 of this wave's 64 columns).  Plain row-major [M][N] tensors.
+    // Every residual value is loaded BEFORE the first store: x is updated in place, and stores the compiler must
+    // assume may alias the next load would serialise the epilogue into one memory round trip per tile.
+    f32x4 res[MT][NT];
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+      const int m = mw0 + tm * 16 + (lane & 15);
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        res[tm][tn] = (m < m_end && n < d.N) ? *reinterpret_cast<const f32x4*>(d.resid + (long)m * d.N + n)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+      const int m = mw0 + tm * 16 + (lane & 15);
+      if (m >= m_end) continue;
+      float s1 = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        f32x4 v = acc[tn][tm] + res[tm][tn];
+        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        acc[tn][tm] = v;
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        if (n < d.N) {
+          *reinterpret_cast<f32x4*>(d.out_f32 + (long)m * d.N + n) = v;
+          op16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            op16_t h, l;
+            dsn_split(v[r], h, l, F16);
+            hi[r] = h;
+            lo[r] = l;
+          }
+          *reinterpret_cast<op16x4*>(d.out_planes + (long)m * d.N + n) = hi;
+          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + (long)m * d.N + n) = lo;
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean = s1 * (1.f / (NT * 16));
+      float m2 = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dl = acc[tn][tm][r] - mean;
+          m2 += dl * dl;
+        }
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if ((lane >> 4) == 0)
+        *reinterpret_cast<float2*>(d.stat_out + ((long)m * d.stat_np + nw0 / (NT * 16)) * 2) = float2{mean, m2};
+    }
+    return;
+  }
+  if constexpr ((EPI & EPI_LNFOLD) != 0) {
+    // Folded-LayerNorm SwiGLU consumer: LN(x') W^T = rstd (x' (W diag gamma)^T - mean colsum) + bias', then
+    // value * silu(gate) -> operand planes [M][N/2].  Column vectors are loaded once, rows then stream out.
+#pragma unroll
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      const int np = nw0 + tp * 32;
+      if (np >= d.N) continue;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + nq);
+      const f32x4 cg = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + 16 + nq);
+      const f32x4 bv = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 bg = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const int m = mw0 + tm * 16 + (lane & 15);
+        if (m >= m_end) continue;
+        const float mu = ln_rows[2 * (m - ln_m0)], rs = ln_rows[2 * (m - ln_m0) + 1];
+        const f32x4 val = (acc[2 * tp][tm] - cv * mu) * rs + bv;
+        const f32x4 gate = (acc[2 * tp + 1][tm] - cg * mu) * rs + bg;
+        op16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          op16_t h, l;
+          dsn_split(val[r] * dsn_silu(gate[r]), h, l, F16);
+          hi[r] = h;
+          lo[r] = l;
+        }
+        const long off = (long)m * (d.N >> 1) + (np >> 1) + nq;
+        *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
+        if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
       }
     }
     return;
@@ -141,33 +237,11 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
           *reinterpret_cast<op16x4*>(d.out_planes + off) = hi;
           if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + off) = lo;
         }
-        if (d.stat_out) acc[tn][tm] = v;  // keep x' for the row statistics below
       }
-      if (d.stat_out) {
-        // (mean, M2) of this row's 64 columns held by the wave: 16 values per lane x the 4 lane groups of the row
-        float s1 = 0.f;
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn) s1 += (acc[tn][tm][0] + acc[tn][tm][1]) + (acc[tn][tm][2] + acc[tn][tm][3]);
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        const float mean = s1 * (1.f / (NT * 16));
-        float m2 = 0.f;
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float dl = acc[tn][tm][r] - mean;
-            m2 += dl * dl;
-          }
-        m2 += __shfl_xor(m2, 16, 64);
-        m2 += __shfl_xor(m2, 32, 64);
-        if ((lane >> 4) == 0)
-          *reinterpret_cast<float2*>(d.stat_out + ((long)m * d.stat_np + nw0 / (NT * 16)) * 2) = float2{mean, m2};
-      }
-    } else if (d.out_fp8) {
+    } else if ((EPI & EPI_FP8OUT) && d.out_fp8) {
       // SwiGLU with fp8 (MX) output: the wave's 64 packed columns are 32 output features = ONE scale block of this
       // row: amax over the lane's 8 values and the 4 lane groups that share the row, E8M0 scale, saturated e4m3
-      static_assert(NT == 4, "fp8 SwiGLU epilogue expects 64 packed columns per wave");
+      static_assert(!(EPI & EPI_FP8OUT) || NT == 4, "fp8 SwiGLU epilogue expects 64 packed columns per wave");
       f32x4 h[2];
       float amax = 0.f;
 #pragma unroll
@@ -204,13 +278,6 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         const int feat = (np >> 1) + nq;
         const long off = row_abs + feat;
         f32x4 val = acc[2 * tp][tm], gate = acc[2 * tp + 1][tm];
-        if (ln_rows) {  // folded LayerNorm: rstd * (x' W^T - mean * colsum)
-          const float mu = ln_rows[2 * (m - ln_m0)], rs = ln_rows[2 * (m - ln_m0) + 1];
-          const f32x4 cv = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + nq);
-          const f32x4 cg = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + 16 + nq);
-          val = (val - cv * mu) * rs;
-          gate = (gate - cg * mu) * rs;
-        }
         if (d.bias) {
           val += *reinterpret_cast<const f32x4*>(d.bias + np + nq);
           gate += *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq);
@@ -642,7 +709,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 // masked.  Staging / ring / swizzle as in igemm2_kernel (BK = 32); row groups are dealt round-robin
 // to the waves, so the per-wave glds count (and its vmcnt) differs by one between waves.
 // ============================================================================
-template <int P, int F16, int WN_, int NST, int TBK, int MT = 17>
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0>
 __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const GemmDesc d,
                                                                          const op16_t* __restrict__ zero_page) {
   // 4 wave rows x WN_ wave columns; the MT row sub-tiles of a panel are dealt MT/4 (+1 for the first MT%4 wave rows):
@@ -747,17 +814,21 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
   // order (Chan's parallel formula) -> LDS behind the ring; the first k-tile's barrier publishes them long before
   // the epilogue reads them
   float* const ln_rows = reinterpret_cast<float*>(lds + NST * STAGE_ELEMS);
-  if (d.ln_stats) {
+  if ((EPI & EPI_LNFOLD) && d.ln_stats) {
     for (int r = tid; r < m_end - m0; r += NWAVES * 64) {
-      const float2* ps = reinterpret_cast<const float2*>(d.ln_stats) + (long)(m0 + r) * d.ln_np;
-      float msum = 0.f, m2 = 0.f;
-      for (int p2 = 0; p2 < d.ln_np; ++p2) msum += ps[p2].x;
+      const f32x4* ps = reinterpret_cast<const f32x4*>(d.ln_stats + (long)(m0 + r) * d.ln_np * 2);  // 2 slices each
+      float msum = 0.f, m2 = 0.f, q = 0.f;
+      // sum of slice means, of slice M2s and of squared slice means in ONE pass (fixed order):
+      // M2 = sum M2_p + cnt * (sum mean_p^2 - np * mean^2)
+      for (int p2 = 0; p2 < d.ln_np / 2; ++p2) {
+        const f32x4 v = ps[p2];
+        msum += v[0] + v[2];
+        m2 += v[1] + v[3];
+        q += v[0] * v[0] + v[2] * v[2];
+      }
       const float mean = msum / (float)d.ln_np;
       const float cnt = (float)(d.Cin * d.taps) / (float)d.ln_np;  // columns per slice
-      for (int p2 = 0; p2 < d.ln_np; ++p2) {
-        const float dm = ps[p2].x - mean;
-        m2 += ps[p2].y + cnt * dm * dm;
-      }
+      m2 += cnt * fmaxf(q - (float)d.ln_np * mean * mean, 0.f);
       ln_rows[2 * r] = mean;
       ln_rows[2 * r + 1] = rsqrtf(m2 / (float)(d.Cin * d.taps) + d.ln_eps);
     }
@@ -811,8 +882,8 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
     }
   }
   // rows m0 + my_row0 + tm*16 ...; wave rows 1..3 never touch their (unused) 5th sub-tile: mask it by row
-  epilogue_gen<P, F16, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z,
-                               d.ln_stats ? ln_rows : nullptr, m0);
+  epilogue_gen<P, F16, 4, MTW, EPI>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane,
+                                    z, ((EPI & EPI_LNFOLD) && d.ln_stats) ? ln_rows : nullptr, m0);
 }
 
 
@@ -984,7 +1055,8 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
       sa = nsa;
     }
   }
-  epilogue_gen<1, 1, 4, MTW>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z);
+  epilogue_gen<1, 1, 4, MTW, EPI_FP8OUT>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64,
+                                         lane, z);
 }
 
 const op16_t* zero_page() {
@@ -1085,20 +1157,20 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
 }
 
 // Row-panel launcher: d.panel_rows rows per workgroup (<= 272), bn in {128, 256}.
-template <int P, int F16, int WN_, int NST, int TBK, int MT = 17>
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0>
 static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t) + (d.ln_stats ? MT * 16 * 2 * sizeof(float) : 0);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
+  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
                      zp);
   return hipGetLastError();
 }
@@ -1154,26 +1226,28 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
   if (d.ln_stats && (!d.swiglu || !d.ln_colsum || d.ln_np <= 0 || d.taps != 1 || planes != 1)) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define PCFG(P_, W_, NS_, BK_)                                                                   \
-  if (planes == P_ && bn == W_ * 64)                                                             \
-    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_>(d, zp, stream);
-#define PCFGS(MT_, P_, W_, NS_, BK_)                                                  \
-  if (planes == P_ && bn == W_ * 64)                                                  \
-    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, MT_>(d, zp, stream) : launch_panel_t<P_, 0, W_, NS_, BK_, MT_>(d, zp, stream);
+  const int epi = (d.stat_out ? EPI_STATS : 0) | (d.ln_stats ? EPI_LNFOLD : 0);
+#define PCFGE(MT_, P_, W_, NS_, BK_, E_)                                                             \
+  if (planes == P_ && bn == W_ * 64 && epi == E_)                                                     \
+    return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, MT_, E_>(d, zp, stream)                          \
+               : launch_panel_t<P_, 0, W_, NS_, BK_, MT_, E_>(d, zp, stream);
+#define PCFGS(MT_, P_, W_, NS_, BK_) PCFGE(MT_, P_, W_, NS_, BK_, 0)
   if (d.panel_rows <= 5 * 16) {  // 66-row panels x 128 columns: the N = D residual-stream GEMMs without split-K
-    PCFGS(5, 1, 2, 4, 64)
+    PCFGE(5, 1, 2, 4, 64, EPI_STATS) PCFGS(5, 1, 2, 4, 64)
   }
   if (d.panel_rows <= 7 * 16) {  // 112-row panels (single-plane modes)
-    PCFGS(7, 1, 4, 3, 64)
+    PCFGS(7, 1, 4, 3, 64) PCFGE(7, 1, 4, 3, 64, EPI_LNFOLD)
   }
   if (d.panel_rows <= 9 * 16) {  // short panels (e.g. 16 x 132 rows): 9 row sub-tiles, a 3-stage ring fits
     PCFGS(9, 1, 4, 3, 64) PCFGS(9, 1, 2, 3, 64) PCFGS(9, 2, 4, 2, 32) PCFGS(9, 2, 2, 2, 32)
+    PCFGE(9, 1, 4, 3, 64, EPI_LNFOLD)
   }
   if (d.panel_rows <= 13 * 16) {  // 13 sub-tiles (large batches: two rounds of 208-row panels)
-    PCFGS(13, 1, 4, 2, 64) PCFGS(13, 1, 2, 2, 64)
+    PCFGS(13, 1, 4, 2, 64) PCFGS(13, 1, 2, 2, 64) PCFGE(13, 1, 4, 2, 64, EPI_LNFOLD)
   }
+  PCFGS(17, 1, 4, 2, 64) PCFGS(17, 1, 2, 2, 64) PCFGS(17, 2, 4, 2, 32) PCFGS(17, 2, 2, 2, 32)
+  PCFGE(17, 1, 4, 2, 64, EPI_LNFOLD)
 #undef PCFGS
-  PCFG(1, 4, 2, 64) PCFG(1, 2, 2, 64) PCFG(2, 4, 2, 32) PCFG(2, 2, 2, 32)
-#undef PCFG
+#undef PCFGE
   return hipErrorInvalidValue;
 }
