@@ -64,21 +64,10 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
     return;
   }
   if constexpr ((EPI & EPI_STATS) != 0) {
-    // Residual-stream producer (to_out without split-K): x' = acc + bias + x, written in place as fp32, as the raw
+    // Residual-stream producer (to_out without split-K): x' = x + A W^T + bias, written in place as fp32, as the raw
     // operand plane, and summarised per row (mean, M2 of this wave's 64 columns).  Plain row-major [M][N] tensors.
-    // Every residual value is loaded BEFORE the first store: x is updated in place, and stores the compiler must
-    // assume may alias the next load would serialise the epilogue into one memory round trip per tile.
-    f32x4 res[MT][NT];
-#pragma unroll
-    for (int tm = 0; tm < MT; ++tm) {
-      const int m = mw0 + tm * 16 + (lane & 15);
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn) {
-        const int n = nw0 + tn * 16 + nq;
-        res[tm][tn] = (m < m_end && n < d.N) ? *reinterpret_cast<const f32x4*>(d.resid + (long)m * d.N + n)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
+    // The residual x is not read here: the kernel seeded the accumulators with it (C-in of the first MFMAs), so its
+    // load latency hides under the first k-tiles and no load has to wait behind the in-place stores below.
 #pragma unroll
     for (int tm = 0; tm < MT; ++tm) {
       const int m = mw0 + tm * 16 + (lane & 15);
@@ -87,7 +76,7 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
         const int n = nw0 + tn * 16 + nq;
-        f32x4 v = acc[tn][tm] + res[tm][tn];
+        f32x4 v = acc[tn][tm];
         if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
         acc[tn][tm] = v;
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
@@ -809,6 +798,19 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
 #pragma unroll
   for (int s2 = 0; s2 < NST - 1; ++s2)
     if (s2 < nkt) issue(s2);
+
+  if constexpr ((EPI & EPI_STATS) != 0) {
+    // residual-stream producer: the accumulators start from x (plain [M][N] fp32), see the epilogue
+#pragma unroll
+    for (int tm = 0; tm < MTW; ++tm) {
+      const int m = m0 + my_row0 + tm * 16 + (lane & 15);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wave_n * 64 + tn * 16 + (lane >> 4) * 4;
+        if (tm < my_mt && m < m_end && n < d.N) acc[tn][tm] = *reinterpret_cast<const f32x4*>(d.resid + (long)m * d.N + n);
+      }
+    }
+  }
 
   // folded LayerNorm: (mean, rstd) of this panel's rows from the producer's per-slice partials, combined in slice
   // order (Chan's parallel formula) -> LDS behind the ring; the first k-tile's barrier publishes them long before

@@ -193,16 +193,26 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
       }
   }
 
-  // ---- 5. + bias + residual -> x' (fp32) and act_next(x') planes
+  // ---- 5. + bias + residual -> x' (fp32) and act_next(x') planes  (residuals one sub-tile ahead of the in-place
+  // stores: see ru_fused2_kernel)
+  f32x4 res[4], nres[4];
+  auto load_res = [&](int tm, f32x4 (&r)[4]) {
+    const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
+    const long rowoff = seq_off + (long)min(l, d.L - 1) * C;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) r[tn] = *reinterpret_cast<const f32x4*>(d.X + rowoff + wn * 64 + tn * 16 + nq);
+  };
+  load_res(0, res);
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
+    if (tm + 1 < 4) load_res(tm + 1, nres);
     const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
-    if (l >= d.L) continue;
     const long rowoff = seq_off + (long)l * C;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
+      if (l >= d.L) continue;
       const int n = wn * 64 + tn * 16 + nq;
-      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + *reinterpret_cast<const f32x4*>(d.X + rowoff + n);
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + res[tn];
       if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
       if (d.out_planes) {
         op16x4 hi, lo;
@@ -220,6 +230,8 @@ __global__ __launch_bounds__(256, 2) void ru_fused_kernel(const RuDesc d, const 
         if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + rowoff + n) = lo;
       }
     }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) res[tn] = nres[tn];
   }
 }
 
@@ -239,7 +251,7 @@ constexpr int H_ELEMS = TL2 * C;
 constexpr int LDS2_ELEMS = H_ELEMS + 2 * WTILE;  // 80 KB
 
 template <int F16>
-__global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const op16_t* __restrict__ zero_page) {
+__global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];
   const int halo = 3 * d.dil;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -386,15 +398,27 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
   }
 
   // ---- + bias + residual -> x' (fp32) and act_next(x') planes
+  // x' overwrites x in place (out_f32 == X), so the compiler must keep every residual load behind the stores that
+  // precede it in program order: the residuals of row sub-tile tm+1 are therefore loaded BEFORE the stores of tm --
+  // one exposed memory round trip per sub-tile pair instead of one per 16-byte store.
+  f32x4 res[4], nres[4];
+  auto load_res = [&](int tm, f32x4 (&r)[4]) {
+    const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
+    const long rowoff = seq_off + (long)min(l, d.L - 1) * C;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) r[tn] = *reinterpret_cast<const f32x4*>(d.X + rowoff + wn * 64 + tn * 16 + nq);
+  };
+  load_res(0, res);
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
+    if (tm + 1 < 4) load_res(tm + 1, nres);
     const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
-    if (l >= d.L) continue;
     const long rowoff = seq_off + (long)l * C;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
+      if (l >= d.L) continue;
       const int n = wn * 64 + tn * 16 + nq;
-      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + *reinterpret_cast<const f32x4*>(d.X + rowoff + n);
+      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + res[tn];
       if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
       if (d.out_planes) {
         op16x4 hi;
@@ -410,6 +434,8 @@ __global__ __launch_bounds__(512, 2) void ru_fused2_kernel(const RuDesc d, const
         *reinterpret_cast<op16x4*>(d.out_planes + rowoff + n) = hi;
       }
     }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) res[tn] = nres[tn];
   }
 }
 
