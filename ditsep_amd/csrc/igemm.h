@@ -37,8 +37,11 @@ struct GemmDesc {
   int resid_row_elems, resid_off;
   const float* bbias;  // per-(batch item, channel) bias [B][bbias_stride] or null (time-embedding bias)
   int bbias_stride;
-  // GroupNorm statistics of the fp32 output, accumulated by the epilogue (atomics) into gn_stats[B][gn_G][2] =
-  // (sum, sum of squares) per (item, group of gn_cpg channels); needs rows_per_b % 64 == 0.  null = off
+  // GroupNorm statistics of the fp32 output, written by the epilogue WITHOUT atomics: gn_stats[B][S][N/4][2] holds,
+  // per item, per 64-row slice s of the item (S = rows_per_b / 64) and per 4-channel quad, (mean, sum of squared
+  // deviations from that mean) of the 256 values -- exact two-pass values from the accumulator registers.  The
+  // consumer (gn_apply) combines the slices x quads of a group in a fixed order (Chan's parallel formula):
+  // bit-reproducible, no E[x^2] - E[x]^2 cancellation.  Needs rows_per_b % 64 == 0, N % 4 == 0.  null = off
   float* gn_stats;
   int gn_G, gn_cpg;
   float* out_f32;      // or null

@@ -145,9 +145,9 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
     }
     return;
   }
-  float gs[NT], gss[NT];  // GroupNorm partial sums of this lane's 4 channels per column sub-tile
+  float gs[NT];  // GroupNorm partial sums of this lane's 4 channels per column sub-tile
 #pragma unroll
-  for (int tn = 0; tn < NT; ++tn) gs[tn] = gss[tn] = 0.f;
+  for (int tn = 0; tn < NT; ++tn) gs[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
     const int m = mw0 + tm * 16 + (lane & 15);
@@ -190,7 +190,7 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         v *= d.out_scale;
         if (d.gn_stats) {
           gs[tn] += (v[0] + v[1]) + (v[2] + v[3]);
-          gss[tn] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          acc[tn][tm] = v;  // kept for the second (deviation) pass below
         }
         if (d.out_f32) {
           f32x4 o = v;
@@ -285,23 +285,31 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
     }
   }
   if (d.gn_stats && mw0 < m_end) {
-    // the wave's rows (a 64-aligned run, rows_per_b % 64 == 0) belong to one item; reduce over the 16 row lanes,
-    // then one atomic pair per (column sub-tile, 4-channel lane group)
+    // the wave's rows are one whole 64-row slice of one item (rows_per_b % 64 == 0): per (column sub-tile, 4-channel
+    // lane group) mean over the 16 row lanes x MT sub-tiles x 4 channels, then the squared deviations, one plain
+    // store per quad -- no atomics, every launch writes the same bits
     const int b = mw0 / d.rows_per_b;
+    const int slice = (mw0 - b * d.rows_per_b) >> 6;
+    const int S = d.rows_per_b >> 6;
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) {
-      float s = gs[tn], ss = gss[tn];
+      float s = gs[tn];
 #pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-      }
+      for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * (1.f / (MT * 64));
+      float m2 = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dl = acc[tn][tm][r] - mean;
+          m2 += dl * dl;
+        }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, 64);
       const int n = nw0 + tn * 16 + nq;
-      if ((lane & 15) == 0 && n < d.N) {
-        float* st = d.gn_stats + ((long)b * d.gn_G + n / d.gn_cpg) * 2;
-        atomicAdd(st, s);
-        atomicAdd(st + 1, ss);
-      }
+      if ((lane & 15) == 0 && n < d.N)
+        *reinterpret_cast<float2*>(d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2) = float2{mean, m2};
     }
   }
 }

@@ -92,7 +92,7 @@ void launch_snake_params(const float* alpha, const float* beta, float* a_out, fl
 void launch_ncsn_pack(const float* xt, const float* mix, int B, int n, int H, int T, int Wp, int Cp, float* of,
                       op16_t* op, long ps, int planes, hipStream_t s);
 void launch_gn_stats(const float* x, long bstride, int rstride, int C, int G, int B, int HW, float* stats,
-                     hipStream_t s);   // stats [B][G][2] = (sum, sum of squares), ACCUMULATED: caller zeroes them
+                     hipStream_t s);   // stats [B][ceil(HW/64)][C/4][2] = (mean, M2) per 64-row slice and channel quad
 void launch_gn_apply(const float* x, long bstride, int rstride, int C, int G, int B, int HW, const float* stats,
                      const float* gamma, const float* beta, float eps, int silu, float* of, op16_t* op, long ps,
                      int planes, hipStream_t s);

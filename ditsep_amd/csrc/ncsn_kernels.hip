@@ -5,6 +5,7 @@
 // form), Gaussian-Fourier time features, input packing and the final 1x1 output layer.
 // All HBM-bound byte movers: 16-byte channel-contiguous accesses.
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -53,59 +54,77 @@ __global__ void ncsn_pack_kernel(const float* __restrict__ xt, const float* __re
   }
 }
 
-// per-(item, group) sum and sum of squares, accumulated with float atomics into stats[B][G][2]
-__global__ void gn_stats_kernel(const float* __restrict__ x, long bstride, int rstride, int C, int G, int HW,
-                                int rows_per_block, float* __restrict__ stats) {
-  __shared__ float ls[64], lss[64];
-  const int b = blockIdx.y;
-  const int row0 = blockIdx.x * rows_per_block;
+// GroupNorm statistics as slice partials: stats[B][S][C/4][2] = (mean, M2) of the (<= 64 rows) x 4 channels of slice
+// s = rows [64 s, 64 s + 64) of the item, quad q -- the layout the GEMM epilogue writes for tensors it produces
+// (GemmDesc::gn_stats).  One thread per (slice, quad): two passes over its <= 256 values, plain stores.
+__global__ void gn_stats_kernel(const float* __restrict__ x, long bstride, int rstride, int C, int HW,
+                                float* __restrict__ stats) {
   const int nq = C >> 2;
-  const int cpg = C / G;
-  if (threadIdx.x < 64) {
-    ls[threadIdx.x] = 0.f;
-    lss[threadIdx.x] = 0.f;
-  }
-  __syncthreads();
-  const int rpp = blockDim.x / nq;  // rows per pass
-  const int q = threadIdx.x % nq, rr = threadIdx.x / nq;
-  float s = 0.f, ss = 0.f;
-  if (rr < rpp) {
-    const int rend = min(row0 + rows_per_block, HW);
-    for (int r = row0 + rr; r < rend; r += rpp) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bstride + (long)r * rstride + q * 4);
+  const int S = (HW + 63) >> 6;
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * nq; i += gridDim.x * blockDim.x) {
+    const int sl = i / nq, q = i - sl * nq;
+    const int r0 = sl * 64, r1 = min(r0 + 64, HW);
+    const float* xp = x + (long)b * bstride + q * 4;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)r * rstride);
       s += (v[0] + v[1]) + (v[2] + v[3]);
-      ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    const int g = (q * 4) / cpg;
-    atomicAdd(&ls[g], s);
-    atomicAdd(&lss[g], ss);
-  }
-  __syncthreads();
-  if (threadIdx.x < G) {
-    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 0], ls[threadIdx.x]);
-    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 1], lss[threadIdx.x]);
+    const float mean = s / (float)((r1 - r0) * 4);
+    float m2 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)r * rstride);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m2 += (v[k] - mean) * (v[k] - mean);
+    }
+    *reinterpret_cast<float2*>(stats + (((long)b * S + sl) * nq + q) * 2) = float2{mean, m2};
   }
 }
 
-// y = (x - mean) * rstd * gamma + beta [, SiLU]  ->  contiguous [B][HW][C] fp32 and/or planes
+// y = (x - mean) * rstd * gamma + beta [, SiLU]  ->  contiguous [B][HW][C] fp32 and/or planes.
+// grid (row chunks, B): a block first combines the slice partials of its item's G groups (fixed order, Chan's
+// parallel formula: M2 = sum M2_p + sum n_p (mean_p - mean)^2) into LDS, then streams its rows.
 __global__ void gn_apply_kernel(const float* __restrict__ x, long bstride, int rstride, int C, int G, int HW,
                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int silu, float* __restrict__ of,
-                                op16_t* __restrict__ op, long ps, int planes, long total4) {
+                                op16_t* __restrict__ op, long ps, int planes, int rows_per_block) {
+  __shared__ float gm[64], gr[64];
   const int nq = C >> 2;
-  const int cpg = C / G;
-  const float inv_n = 1.f / ((float)HW * (float)cpg);
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+  const int cpg = C / G, qpg = cpg >> 2;
+  const int S = (HW + 63) >> 6;
+  const int b = blockIdx.y;
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x;
+    const float2* sp = reinterpret_cast<const float2*>(stats) + (long)b * S * nq + g * qpg;
+    float wsum = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
+      for (int q = 0; q < qpg; ++q) wsum += cnt * sp[(long)sl * nq + q].x;
+    }
+    const float ntot = (float)HW * (float)cpg;
+    const float mean = wsum / ntot;
+    float m2 = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
+      for (int q = 0; q < qpg; ++q) {
+        const float2 pr = sp[(long)sl * nq + q];
+        const float dm = pr.x - mean;
+        m2 += pr.y + cnt * dm * dm;
+      }
+    }
+    gm[g] = mean;
+    gr[g] = rsqrtf(m2 / ntot + eps);
+  }
+  __syncthreads();
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(r_begin + rows_per_block, HW);
+  const long total4 = (long)(r_end - r_begin) * nq;
+  for (long i = threadIdx.x; i < total4; i += blockDim.x) {
     const int q = (int)(i % nq);
-    const long br = i / nq;
-    const int r = (int)(br % HW);
-    const long b = br / HW;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + b * bstride + (long)r * rstride + q * 4);
+    const int r = r_begin + (int)(i / nq);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bstride + (long)r * rstride + q * 4);
     const int g = (q * 4) / cpg;
-    const float s = stats[(b * G + g) * 2], ss = stats[(b * G + g) * 2 + 1];
-    const float mean = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
+    const float mean = gm[g], rstd = gr[g];
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + q * 4);
     const f32x4 be = *reinterpret_cast<const f32x4*>(beta + q * 4);
     f32x4 o;
@@ -114,8 +133,9 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, long bstride, int r
       float t = (v[k] - mean) * rstd * ga[k] + be[k];
       o[k] = silu ? dsn_silu(t) : t;
     }
-    if (of) reinterpret_cast<f32x4*>(of)[i] = o;
-    if (op) store_planes4(op, ps, planes, i * 4, o);
+    const long oi = ((long)b * HW + r) * nq + q;
+    if (of) reinterpret_cast<f32x4*>(of)[oi] = o;
+    if (op) store_planes4(op, ps, planes, oi * 4, o);
   }
 }
 
@@ -220,17 +240,18 @@ void launch_ncsn_pack(const float* xt, const float* mix, int B, int n, int H, in
 }
 void launch_gn_stats(const float* x, long bstride, int rstride, int C, int G, int B, int HW, float* stats,
                      hipStream_t st) {
-  if (C / 4 > TPB || G > 64 || C % (4 * G) != 0) return;  // unsupported shape: caller validates (engine: C <= 1024)
-  const int rows_per_block = 64;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + rows_per_block - 1) / rows_per_block, B), dim3(TPB), 0, st, x, bstride,
-                     rstride, C, G, HW, rows_per_block, stats);
+  if (G > 64 || C % (4 * G) != 0) return;  // unsupported shape: caller validates (engine: C <= 1024)
+  const int S = (HW + 63) / 64;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv((long)S * (C / 4), 64), B), dim3(64), 0, st, x, bstride, rstride, C, HW,
+                     stats);
 }
 void launch_gn_apply(const float* x, long bstride, int rstride, int C, int G, int B, int HW, const float* stats,
                      const float* gamma, const float* beta, float eps, int silu, float* of, op16_t* op, long ps,
                      int planes, hipStream_t st) {
-  const long total4 = (long)B * HW * (C / 4);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, bstride, rstride, C, G, HW, stats,
-                     gamma, beta, eps, silu, of, op, ps, planes, total4);
+  // enough blocks to fill the chip, each with at least ~4k elements behind its statistics prologue
+  const int rows_per_block = std::max(cdiv(4096, C), cdiv((long)HW * B, 2048));
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(HW, rows_per_block), B), dim3(TPB), 0, st, x, bstride, rstride, C, G, HW,
+                     stats, gamma, beta, eps, silu, of, op, ps, planes, rows_per_block);
 }
 void launch_fir2d(const float* x, long bstride, int rstride, int C, int B, int H, int W, int up, const float* add,
                   float* of, op16_t* op, long ps, int planes, hipStream_t st) {

@@ -420,7 +420,34 @@ def test_ncsnpp_full_size_vs_oracle():
     t = torch.tensor([0.9, 0.05])
     ref = oncs.NCSNppScore(sd, cfg)(xt, t, mix)
     eng = make_engine(ncfg=cfg, nsd=sd, precision=X3)
-    assert rel_l2(eng.score(xt, t, mix), ref) < 2e-4
+    out = eng.score(xt, t, mix)
+    assert rel_l2(out, ref) < 2e-4
+    # GroupNorm statistics are slice partials combined in a fixed order (no float atomics): bit-reproducible
+    for _ in range(3):
+        assert torch.equal(eng.score(xt, t, mix), out)
+    # ... and exact two-pass deviations instead of E[x^2] - E[x]^2: a large common offset on the input (every
+    # GroupNorm of the stem sees mean >> spread) must not cost accuracy
+    eng.close()
+
+
+def test_ncsnpp_groupnorm_large_offset_and_ragged_slices():
+    """GroupNorm statistics: (mean, M2) slice partials + Chan's combine.  A tiny NCSN++ driven with inputs whose mean
+    is 300x their spread (the cancellation case of E[x^2] - E[x]^2 in fp32) still matches the oracle, and so does a
+    frame count whose H*W is not a multiple of the 64-row slice (the stats-kernel path with a ragged last slice)."""
+    from oracle import ncsnpp as oncs
+
+    cfg = oncs.NCSNppConfig(n_src=2, nf=32)
+    sd = oncs.random_ncsnpp_weights(cfg, 41)
+    eng = make_engine(ncfg=cfg, nsd=sd, precision=X3)
+    g = torch.Generator().manual_seed(9)
+    for T, offset in ((8, 300.0), (6, 0.0), (6, 300.0)):
+        xt = offset + torch.randn((2, 2, 64, T), generator=g)
+        mix = offset + torch.randn((2, 1, 64, T), generator=g)
+        t = torch.tensor([0.8, 0.1])
+        ref = oncs.NCSNppScore(sd, cfg)(xt, t, mix)
+        out = eng.score(xt, t, mix)
+        assert rel_l2(out, ref) < 5e-4, (T, offset, rel_l2(out, ref))
+        assert torch.equal(eng.score(xt, t, mix), out)
     eng.close()
 
 
