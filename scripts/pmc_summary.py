@@ -1,26 +1,56 @@
-"""Aggregate rocprofv3 --pmc counter CSVs (separate FETCH_SIZE / WRITE_SIZE passes over
-scripts/pmc_workload.py) into HBM bytes of the implicit-GEMM kernels (incl. the fused ResidualUnit) per DiT score call and per decode,
-and write profiles/<tag>.json.  gfx950 corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE
-tallies 64 B per 128-B request of wide coalesced reads -> doubled; WRITE_SIZE exact; both in KiB."""
-import csv, glob, json, sys
+"""Aggregate rocprofv3 --pmc counter CSVs (separate FETCH_SIZE / WRITE_SIZE passes over scripts/pmc_workload.py with
+PART=score and PART=decode) into HBM bytes per launch of each kernel, per DiT score call and per decode, and write
+profiles/<tag>.json.  gfx950 corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 64 B per 128-B
+request of wide coalesced reads -> doubled; WRITE_SIZE exact; both in KiB.
+usage: pmc_summary.py <score_fetch_dir> <score_write_dir> <decode_fetch_dir> <decode_write_dir> <out.json> [commit]"""
+import collections, csv, glob, json, re, sys
+
+SETUP = ("pack_weight", "wn_scale", "snake_params", "packed_row_sum", "bias_plus_wbeta", "pack_bias", "randn", "fill", "copyBuffer",
+         "distribution", "elementwise", "rope_tables")
+# bench.py call site -> substring of the rocprof kernel name at the C2 shape, headline (fp16) mode
+SITES = {"dit.ff_in": "igemm_panel_kernel<1, 1, 4, 2, 64, 17, 2>", "dit.ff_out": "igemm_panel_kernel<1, 1, 4, 3, 64, 9, 0>",
+         "dit.qkv": "igemm_panel_kernel<1, 1, 4, 3, 64, 7, 0>", "dit.attn_out": "igemm_panel_kernel<1, 1, 2, 4, 64, 5, 1>",
+         "dit.residual_norm": "residual_norm_kernel", "dit.attention": "attention_mfma_kernel",
+         "vae.residual_unit_fused": "ru_fused2_kernel"}
+
 
 def load(dirname, counter):
-    rows = []
+    per = collections.defaultdict(list)
     for f in glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and ("igemm" in r["Kernel_Name"] or "ru_fused" in r["Kernel_Name"]):
-                rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-    return [v for _, v in sorted(rows)]
+            if r.get("Counter_Name") != counter:
+                continue
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            if any(s in name for s in SETUP):
+                continue
+            per[name].append(float(r["Counter_Value"]))
+    return per
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-n_dec = 30          # conv_in + 5 x convT + 3 blocks x 3 x (conv7, conv1) + 2 blocks x 3 fused ResidualUnits
-n_score = (len(fetch) - n_dec) // 2
-assert len(fetch) == len(write) == 2 * n_score + n_dec, (len(fetch), len(write))
-def hbm(a, b): return (2 * sum(fetch[a:b]) + sum(write[a:b])) * 1024
-out = {"igemm_launches_per_score_call": n_score, "igemm_launches_per_decode": n_dec,
-       "score_call_hbm_bytes": hbm(n_score, 2 * n_score), "decode_hbm_bytes": hbm(2 * n_score, len(fetch)),
-       "score_call_fetch_kib_raw": sum(fetch[n_score:2 * n_score]), "score_call_write_kib": sum(write[n_score:2 * n_score]),
-       "decode_fetch_kib_raw": sum(fetch[2 * n_score:]), "decode_write_kib": sum(write[2 * n_score:]),
-       "note": "batch 64, T=32; hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1))
+
+def part(fetch_dir, write_dir, calls):
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    rows, total = {}, 0.0
+    for name in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(name, []), write.get(name, [])
+        n = max(len(f), len(w))
+        hbm = (2 * sum(f) + sum(w)) * 1024
+        rows[name] = {"launches": n // calls, "hbm_bytes_per_launch": hbm / max(n, 1),
+                      "fetch_kib_raw_per_launch": sum(f) / max(len(f), 1), "write_kib_per_launch": sum(w) / max(len(w), 1)}
+        total += hbm / calls
+    return rows, total
+
+
+score, score_total = part(sys.argv[1], sys.argv[2], 2)
+decode, decode_total = part(sys.argv[3], sys.argv[4], 1)
+sites = {}
+for site, pat in SITES.items():
+    for table in (score, decode):
+        for name, r in table.items():
+            if pat in name:
+                sites[site] = {"kernel": name, **r}
+out = {"commit": sys.argv[6] if len(sys.argv) > 6 else None,
+       "note": "batch 64, T=32, fp16 headline mode; hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md",
+       "score_call_hbm_bytes": score_total, "decode_hbm_bytes": decode_total, "sites": sites,
+       "score_kernels": score, "decode_kernels": decode}
+json.dump(out, open(sys.argv[5], "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k not in ("score_kernels", "decode_kernels")}, indent=1))
