@@ -20,7 +20,8 @@ def load(dirname, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            name = re.sub(r"\(.*", "", name).strip()
             if any(s in name for s in SETUP):
                 continue
             per[name].append(float(r["Counter_Value"]))
