@@ -960,7 +960,9 @@ struct dsn_ctx {
           d.out_ps = M * D;
           d.stat_out = ST;
           d.stat_np = D / 64;
-          d.m_fast = 1;
+          static const bool out_mfast = getenv("DSN_OUT_MFAST") != nullptr;
+          d.m_fast = out_mfast ? 1 : 0;  // an XCD's share walks ACROSS the 8 column tiles of a few row panels: the whole
+                                         // 2 MB weight and 4 panels fit its L2 (m_fast = 1: every XCD re-fetches all of A)
           run(d, st, 128);
           pend_n = 0;
           pend_bias = nullptr;
@@ -1252,6 +1254,19 @@ struct dsn_ctx {
         d.out_planes = pb;
         d.out_ps = o_ps;
         set_act(d, b.ru[0].act0);
+        {
+          // Shallow-K phase GEMMs (the last up-sampling layers: K = 2 x 128 or 2 x 256, output 6 B per element) are
+          // store-bound: a 3-stage 256 x 128 tile beats the 256 x 256 default there
+          static const char* ct = getenv("DSN_CONVT_TILE");  // "bm,bn,nst,bk" (development)
+          int bm = 256, bn = 128, nstg = 3, bk = 64;  // measured: 256x128x3 8.3 ms, 256x256x2 9.2 ms, 128x128x3 13.4 ms (5 launches)
+          if (ct) sscanf(ct, "%d,%d,%d,%d", &bm, &bn, &nstg, &bk);
+          if (P == 1 && d.taps * d.Cin <= 512 && d.Cin % bk == 0 && bm > 0) {
+            d.cfg_bm = bm;
+            d.cfg_bn = bn;
+            d.cfg_nst = nstg;
+            d.cfg_bk = bk;
+          }
+        }
         run(d, st);
       }
       for (int j = 0; j < 3; ++j) {
