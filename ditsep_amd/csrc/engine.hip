@@ -698,7 +698,7 @@ struct dsn_ctx {
     k = std::min(k, std::min(8, nkt / 8));
     return std::max(k, 1);
   }
-  void run(const GemmDesc& d, hipStream_t st, int panel_bn = 0) {
+  void run(const GemmDesc& d, hipStream_t st, int panel_bn = 0, bool skinny = false) {
     ProfRec pr;
     if (profiling) {
       HIPCHK(hipEventCreate(&pr.a));
@@ -708,8 +708,9 @@ struct dsn_ctx {
       HIPCHK(hipEventRecord(pr.a, st));
     }
     static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
-    hipError_t e = panel_bn > 0 ? igemm_panel_launch(d, PL, panel_bn, st)
-                                : ((use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st));
+    hipError_t e = skinny ? igemm_skinny_launch(d, PL, st)
+                          : (panel_bn > 0 ? igemm_panel_launch(d, PL, panel_bn, st)
+                                          : ((use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st)));
     if (profiling) {
       HIPCHK(hipEventRecord(pr.b, st));
       prof.push_back(pr);
@@ -855,8 +856,12 @@ struct dsn_ctx {
     // folded ff_norm (single-plane modes, panels of at most 80 rows fill whole rounds): to_out runs WITHOUT split-K in
     // 128-column tiles, adds the residual itself and writes x' (fp32), its raw operand plane and per-row statistics;
     // FF-in then applies the LayerNorm algebraically in its epilogue -- the LayerNorm launch between them is gone
+    // one mixture / a handful (M <= 48 token rows, e.g. config C1): weight-streaming skinny kernels, split-K 8 for the
+    // two N = D GEMMs so that every CU streams a share of their weights
+    static const bool no_skinny = getenv("DSN_NO_SKINNY") != nullptr;
+    const bool skinny = !no_skinny && P == 1 && !fp8 && M <= 48 && D % 256 == 0;
     int fold_rows = 0;
-    if (fold_ln && use_panel_ok(D)) {
+    if (fold_ln && use_panel_ok(D) && !skinny) {
       for (int rounds = 1; rounds <= 4 && !fold_rows; ++rounds) {
         const int np = 256 * rounds / std::max(1, cdiv(D, 128));
         if (np >= 1 && cdiv(M, np) <= 80) fold_rows = cdiv(M, np);
@@ -943,6 +948,8 @@ struct dsn_ctx {
         if (fp8) {
           d.panel_rows = panel_rows_for(cdiv(3 * D, 256), 208);
           run_fp8(d, st, 256);
+        } else if (skinny) {
+          run(d, st, 0, true);
         } else {
           run(d, st, qkv_panel);
         }
@@ -970,7 +977,7 @@ struct dsn_ctx {
         static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
         int obn = 128, oks = 2;
         if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
-        d.ksplit = (short_panel || fp8) ? oks : pick_ksplit(d);
+        d.ksplit = skinny ? 8 : ((short_panel || fp8) ? oks : pick_ksplit(d));
         if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks, (fp8 && obn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
@@ -982,6 +989,7 @@ struct dsn_ctx {
           d.out_f32 = X;
         }
         if (fp8) run_fp8(d, st, obn);
+        else if (skinny) run(d, st, 0, true);
         else run(d, st, short_panel ? obn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
         pend_bias = nullptr;
@@ -1024,6 +1032,8 @@ struct dsn_ctx {
         if (fp8) {
           d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256), 144);  // 256-column fp8 tiles: at most 9 row sub-tiles
           run_fp8(d, st, 256);
+        } else if (skinny) {
+          run(d, st, 0, true);
         } else {
           run(d, st, use_panel ? 256 : 0);
         }
@@ -1034,7 +1044,7 @@ struct dsn_ctx {
         static const char* fcfg = getenv("DSN_FF2_CFG");
         int fbn = 256, fks = 4;
         if (fcfg) sscanf(fcfg, "%d,%d", &fbn, &fks);
-        d.ksplit = (short_panel || fp8) ? fks : pick_ksplit(d);
+        d.ksplit = skinny ? 8 : ((short_panel || fp8) ? fks : pick_ksplit(d));
         if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks, (fp8 && fbn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
@@ -1048,6 +1058,7 @@ struct dsn_ctx {
           pend_bias = nullptr;
         }
         if (fp8) run_fp8(d, st, fbn);
+        else if (skinny) run(d, st, 0, true);
         else run(d, st, short_panel ? fbn : 0);
         pend_n = d.ksplit > 1 ? d.ksplit : 0;
       }

@@ -102,6 +102,9 @@ hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nsta
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);
+// skinny variant for M <= 48 rows (single-plane modes, plain row-major GEMM): one wave per 32 columns x split-K,
+// weights streamed straight into MFMA fragments
+hipError_t igemm_skinny_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // the same with fp8 (MX) operands: d.a_scale / d.w_scale set, d.Cin = K/2 (byte pairs), K % 128 == 0
 hipError_t igemm_panel_fp8_launch(const GemmDesc& d, int bn, hipStream_t stream);
 

@@ -1069,6 +1069,60 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
                                          lane, z);
 }
 
+
+// ============================================================================
+// Skinny GEMM for M <= 48 rows (one mixture, or a handful: config C1 is 17 token rows): there the path is bound by
+// streaming the weights once and by launch latency, not by MFMA work, and a tile kernel leaves most CUs idle
+// (QKV at 256-column tiles: 12 workgroups).  One WAVE per workgroup owns 32 output columns (x split-K): its weight
+// rows go straight from global memory into MFMA fragments (each element is used by this wave only: no LDS, no
+// barrier), the few activation rows come from L2 the same way; 8 k-steps of loads are in flight per wave.
+// N / 32 x ksplit waves: QKV 96, FF-in 256, to_out / FF-out 32 x 8 = 256.
+// ============================================================================
+template <int F16, int MT>
+__global__ __launch_bounds__(64) void igemm_skinny_kernel(const GemmDesc d) {
+  constexpr int U = MT <= 2 ? 8 : 4;  // k-steps of 32 per load batch
+  const int lane = threadIdx.x;
+  const int r = lane & 15, q = lane >> 4;
+  const int tiles_n = (d.N + 31) >> 5;
+  const int z = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x - z * tiles_n) * 32;
+  const int K = d.Cin;
+  const int nk = K >> 5;
+  const int kb = (int)((long)nk * z / d.ksplit), ke = (int)((long)nk * (z + 1) / d.ksplit);
+  const op16_t* wp[2];
+  const op16_t* ap[MT];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) wp[tn] = d.W + (long)min(n0 + tn * 16 + r, d.N - 1) * K + q * 8;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm) ap[tm] = d.A + (long)min(tm * 16 + r, d.M - 1) * d.in_row_elems + q * 8;
+  f32x4 acc[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kb; k0 < ke; k0 += U) {
+    op16x8 fw[U][2], fa[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = min(k0 + u, ke - 1);  // tail steps re-read the last tile and are skipped below
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) fw[u][tn] = *reinterpret_cast<const op16x8*>(wp[tn] + ks * 32);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) fa[u][tm] = *reinterpret_cast<const op16x8*>(ap[tm] + ks * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + u < ke) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < MT; ++tm) acc[tn][tm] = mfma16<F16>(fw[u][tn], fa[u][tm], acc[tn][tm]);
+      }
+    }
+  }
+  epilogue_gen<1, F16, 2, MT>(d, acc, 0, d.M, n0, lane, z);
+}
+
 const op16_t* zero_page() {
   static op16_t* zp[64] = {};
   op16_t*& z = zp[dsn_current_device()];
@@ -1221,6 +1275,28 @@ hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t strea
   // x 256-column tile does not fit 256 registers per lane with 32-byte fragments: callers use <= 208 rows there)
   FCFG(7, 4, 4, 3) FCFG(9, 2, 4, 3) FCFG(9, 4, 2, 3) FCFG(13, 2, 4, 2) FCFG(13, 4, 2, 3) FCFG(17, 4, 2, 3)
 #undef FCFG
+  return hipErrorInvalidValue;
+}
+
+hipError_t igemm_skinny_launch(const GemmDesc& din, int pl, hipStream_t stream) {
+  GemmDesc d = din;
+  if (d.ksplit < 1) d.ksplit = 1;
+  if (PL_COUNT(pl) != 1 || d.taps != 1 || d.in_stride != 1 || d.in_pad != 0 || d.rows_per_b != d.M || d.img_w > 0 ||
+      d.M <= 0 || d.M > 48 || d.N <= 0 || d.Cin % 32 != 0 || d.N % 4 != 0 || d.gn_stats || d.stat_out || d.ln_stats ||
+      d.out_fp8)
+    return hipErrorInvalidValue;
+  if (d.swiglu && d.N % 32 != 0) return hipErrorInvalidValue;
+  if (d.ksplit > 1 && (!d.out_f32 || d.swiglu || d.ksplit > d.Cin / 32)) return hipErrorInvalidValue;
+  const int grid = ((d.N + 31) / 32) * d.ksplit;
+  const int mt = (d.M + 15) / 16;
+#define SK(MT_)                                                                                     \
+  if (mt == MT_) {                                                                                  \
+    if (PL_F16(pl)) hipLaunchKernelGGL((igemm_skinny_kernel<1, MT_>), dim3(grid), dim3(64), 0, stream, d); \
+    else hipLaunchKernelGGL((igemm_skinny_kernel<0, MT_>), dim3(grid), dim3(64), 0, stream, d);     \
+    return hipGetLastError();                                                                       \
+  }
+  SK(1) SK(2) SK(3)
+#undef SK
   return hipErrorInvalidValue;
 }
 
