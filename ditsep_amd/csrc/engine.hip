@@ -856,10 +856,13 @@ struct dsn_ctx {
     // folded ff_norm (single-plane modes, panels of at most 80 rows fill whole rounds): to_out runs WITHOUT split-K in
     // 128-column tiles, adds the residual itself and writes x' (fp32), its raw operand plane and per-row statistics;
     // FF-in then applies the LayerNorm algebraically in its epilogue -- the LayerNorm launch between them is gone
-    // one mixture / a handful (M <= 48 token rows, e.g. config C1): weight-streaming skinny kernels, split-K 8 for the
-    // two N = D GEMMs so that every CU streams a share of their weights
+    // one mixture of the C2 / C5 kind (33..48 token rows): weight-streaming skinny kernels, split-K 8 for the two
+    // N = D GEMMs so that every CU streams a share of their weights.  Measured (scripts/score_time.py, one score
+    // call): M = 33: 1.52 ms vs 2.27 ms with the panel kernels; M = 17 (config C1): 2.29 vs 2.06 ms, M = 9: 3.13 ms --
+    // below 33 rows the skinny kernels LOSE (unexplained), so the window starts there (DSN_SKINNY_MIN overrides).
     static const bool no_skinny = getenv("DSN_NO_SKINNY") != nullptr;
-    const bool skinny = !no_skinny && P == 1 && !fp8 && M <= 48 && D % 256 == 0;
+    static const int skinny_min = getenv("DSN_SKINNY_MIN") ? atoi(getenv("DSN_SKINNY_MIN")) : 33;
+    const bool skinny = !no_skinny && P == 1 && !fp8 && M >= skinny_min && M <= 48 && D % 256 == 0;
     int fold_rows = 0;
     if (fold_ln && use_panel_ok(D) && !skinny) {
       for (int rounds = 1; rounds <= 4 && !fold_rows; ++rounds) {

@@ -1073,22 +1073,28 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
 // ============================================================================
 // Skinny GEMM for M <= 48 rows (one mixture, or a handful: config C1 is 17 token rows): there the path is bound by
 // streaming the weights once and by launch latency, not by MFMA work, and a tile kernel leaves most CUs idle
-// (QKV at 256-column tiles: 12 workgroups).  One WAVE per workgroup owns 32 output columns (x split-K): its weight
+// (QKV at 256-column tiles: 12 workgroups).  A 4-wave workgroup owns 32 output columns (x split-K): its weight
 // rows go straight from global memory into MFMA fragments (each element is used by this wave only: no LDS, no
 // barrier), the few activation rows come from L2 the same way; 8 k-steps of loads are in flight per wave.
-// N / 32 x ksplit waves: QKV 96, FF-in 256, to_out / FF-out 32 x 8 = 256.
+// N / 32 x ksplit workgroups: QKV 96, FF-in 256, to_out / FF-out 32 x 8 = 256.
 // ============================================================================
 template <int F16, int MT>
-__global__ __launch_bounds__(64) void igemm_skinny_kernel(const GemmDesc d) {
-  constexpr int U = MT <= 2 ? 8 : 4;  // k-steps of 32 per load batch
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void igemm_skinny_kernel(const GemmDesc d) {
+  // 4 waves per workgroup split its K range (more loads in flight per CU: the kernel is one HBM round trip long);
+  // their partial tiles are summed through LDS in wave order (deterministic) by wave 0, which runs the epilogue
+  constexpr int KW = 4;
+  constexpr int U = 4;  // k-steps of 32 per load batch (8 was 3x slower at MT = 2: measured)
+  __shared__ f32x4 red[KW - 1][2 * MT][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int tiles_n = (d.N + 31) >> 5;
   const int z = blockIdx.x / tiles_n;
   const int n0 = (blockIdx.x - z * tiles_n) * 32;
   const int K = d.Cin;
   const int nk = K >> 5;
-  const int kb = (int)((long)nk * z / d.ksplit), ke = (int)((long)nk * (z + 1) / d.ksplit);
+  const int kb0 = (int)((long)nk * z / d.ksplit), ke0 = (int)((long)nk * (z + 1) / d.ksplit);
+  const int kb = kb0 + (int)((long)(ke0 - kb0) * wave / KW), ke = kb0 + (int)((long)(ke0 - kb0) * (wave + 1) / KW);
   const op16_t* wp[2];
   const op16_t* ap[MT];
 #pragma unroll
@@ -1120,6 +1126,20 @@ __global__ __launch_bounds__(64) void igemm_skinny_kernel(const GemmDesc d) {
       }
     }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) red[wave - 1][tn * MT + tm][lane] = acc[tn][tm];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) acc[tn][tm] += red[w][tn * MT + tm][lane];
   epilogue_gen<1, F16, 2, MT>(d, acc, 0, d.M, n0, lane, z);
 }
 
@@ -1291,8 +1311,8 @@ hipError_t igemm_skinny_launch(const GemmDesc& din, int pl, hipStream_t stream) 
   const int mt = (d.M + 15) / 16;
 #define SK(MT_)                                                                                     \
   if (mt == MT_) {                                                                                  \
-    if (PL_F16(pl)) hipLaunchKernelGGL((igemm_skinny_kernel<1, MT_>), dim3(grid), dim3(64), 0, stream, d); \
-    else hipLaunchKernelGGL((igemm_skinny_kernel<0, MT_>), dim3(grid), dim3(64), 0, stream, d);     \
+    if (PL_F16(pl)) hipLaunchKernelGGL((igemm_skinny_kernel<1, MT_>), dim3(grid), dim3(256), 0, stream, d); \
+    else hipLaunchKernelGGL((igemm_skinny_kernel<0, MT_>), dim3(grid), dim3(256), 0, stream, d);     \
     return hipGetLastError();                                                                       \
   }
   SK(1) SK(2) SK(3)
