@@ -861,7 +861,8 @@ struct dsn_ctx {
     // call): M = 33: 1.52 ms vs 2.27 ms with the panel kernels; M = 17 (config C1): 2.29 vs 2.06 ms, M = 9: 3.13 ms --
     // below 33 rows the skinny kernels LOSE (unexplained), so the window starts there (DSN_SKINNY_MIN overrides).
     static const bool no_skinny = getenv("DSN_NO_SKINNY") != nullptr;
-    static const int skinny_min = getenv("DSN_SKINNY_MIN") ? atoi(getenv("DSN_SKINNY_MIN")) : 33;
+    const char* skm = getenv("DSN_SKINNY_MIN");  // read per call: tests drive the 1- / 2-sub-tile variants with it
+    const int skinny_min = skm ? atoi(skm) : 33;
     const bool skinny = !no_skinny && P == 1 && !fp8 && M >= skinny_min && M <= 48 && D % 256 == 0;
     int fold_rows = 0;
     if (fold_ln && use_panel_ok(D) && !skinny) {
