@@ -1218,6 +1218,139 @@ struct dsn_ctx {
     return o.denoise ? xm : x;
   }
 
+  // ---------------------------------------------------------------- secondary sampler family
+  // MixSDE / PriorMixSDE predictor-corrector loop with the ald2 corrector (reference sdes.py:182-593,
+  // correctors.py:87-121, __init__.py:133-193) on the latent state read as [B, n, D*T]; scalar schedules in fp32 as
+  // torch evaluates them on a [B]-vector of equal times.
+  struct MixOpts {
+    int prior_mix = 0, avg_len = 510, pred = DSN_PRED_REVERSE_DIFFUSION, corr = DSN_MIXCORR_ALD2, c = 1, denoise = 1;
+    float d_lambda = 2.f, sigma_min = 0.05f, sigma_max = 0.5f, snr = 0.5f, t_eps = 0.03f;
+    long draws(int N) const { return 1 + (long)N * (c + (pred == DSN_PRED_NONE ? 0 : 1)); }
+  };
+  static void mix_eigval(const MixOpts& o, float t, float& ev1, float& ev2) {
+    const double ratio = (double)o.sigma_max / o.sigma_min, logsig = log(ratio);
+    const float mult = (float)((double)o.sigma_min * o.sigma_min);
+    const float srp = powf((float)ratio, 2.f * t);
+    ev1 = mult * (srp - 1.f);
+    ev2 = mult * (srp - expf((float)(-2.0 * o.d_lambda) * t)) / (float)(1.0 + o.d_lambda / logsig);
+  }
+  float* pc_sample_mix(const float* y, const float* noise, int B, int T, int N, const MixOpts& o, hipStream_t st) {
+    const int n = cfg.n_src, Dl = cfg.latent_dim;
+    const long sz = (long)B * n * Dl * T;
+    float* x = wsbuf<float>("pc_x", sz);
+    float* xm = wsbuf<float>("pc_xm", sz);
+    float* tv = wsbuf<float>("pc_t", (long)B * N);
+    float* smix = o.prior_mix ? wsbuf<float>("pc_smix", (long)B * Dl * T) : nullptr;
+    const Sched s = schedule(N, o.t_eps, o.snr);  // timesteps = linspace(1, eps, N)
+    const float dt = (float)(1.0 / N), sqdt = sqrtf(dt);
+    const double ratio = (double)o.sigma_max / o.sigma_min, logsig = log(ratio);
+    struct CacheScope {
+      TimeCache& c;
+      ~CacheScope() { c = TimeCache(); }
+    } cache_scope{time_cache};
+    {
+      const bool dit = cfg.score_kind == DSN_SCORE_DIT;
+      const int width = dit ? cfg.dit_embed_dim : ncs_dense_total;
+      float* all = wsbuf<float>("te_all", (long)N * B * width);
+      Tag tg(this, "score.time_embed");
+      if (dit) dit_time_embed(tv, N * B, all, st);
+      else ncs_time_dense(tv, N * B, all, st);
+      time_cache.t0 = tv;
+      time_cache.rows = (long)N * B;
+      time_cache.data = all;
+      time_cache.width = width;
+    }
+    if (smix) launch_sigma_mix(y, smix, B, Dl * T, o.avg_len, st);
+    const float* z = noise;
+    float ev1, ev2;
+    mix_eigval(o, 1.f, ev1, ev2);
+    launch_mix_prior(y, z, x, smix, sqrtf(ev1), sqrtf(ev2), B, n, Dl, T, st);
+    z += sz;
+    HIPCHK(hipMemcpyAsync(xm, x, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < N; ++i) {
+      const float* ti = tv + (long)i * B;
+      const float t = s.t[i];
+      if (o.corr == DSN_MIXCORR_ALD2 && o.c > 0) {
+        mix_eigval(o, t, ev1, ev2);
+        for (int k = 0; k < o.c; ++k) {
+          float* sc = score_tokens(x, ti, y, B, T, st);
+          launch_mix_corrector(x, xm, sc, z, smix, sqrtf(ev1), sqrtf(ev2), o.snr, B, n, Dl, T, st);
+          z += sz;
+        }
+      }
+      if (o.pred == DSN_PRED_NONE) {
+        HIPCHK(hipMemcpyAsync(xm, x, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+        continue;
+      }
+      const float g = (float)o.sigma_min * powf((float)ratio, t) * (float)sqrt(2.0 * logsig);
+      float* sc = score_tokens(x, ti, y, B, T, st);
+      launch_mix_predictor(x, xm, sc, z, smix, o.d_lambda, dt, g, sqdt, o.pred == DSN_PRED_EULER_MARUYAMA, B, n, Dl, T, st);
+      z += sz;
+    }
+    return o.denoise ? xm : x;
+  }
+
+  // get_sb_sampler (reference src/sdes/__init__.py:284-389) with SBVESDE (sdes.py:701-779): xt = y repeated over
+  // the sources, N first-order bridge steps over linspace(1, eps, N + 1); the score network's output is the data
+  // estimate.  sde type consumes one noise tensor per step (the last step's weight is zero, the draw still happens).
+  float* sb_sample(const float* y, const float* noise, int B, int T, int N, float k, float c, float sbeps, float t_eps,
+                   int ode, hipStream_t st) {
+    const int n = cfg.n_src, Dl = cfg.latent_dim;
+    const long sz = (long)B * n * Dl * T;
+    float* x = wsbuf<float>("pc_x", sz);
+    float* tv = wsbuf<float>("pc_t", (long)B * N);
+    struct CacheScope {
+      TimeCache& c;
+      ~CacheScope() { c = TimeCache(); }
+    } cache_scope{time_cache};
+    {
+      const bool dit = cfg.score_kind == DSN_SCORE_DIT;
+      const int width = dit ? cfg.dit_embed_dim : ncs_dense_total;
+      float* all = wsbuf<float>("te_all", (long)N * B * width);
+      Tag tg(this, "score.time_embed");
+      if (dit) dit_time_embed(tv, N * B, all, st);
+      else ncs_time_dense(tv, N * B, all, st);
+      time_cache.t0 = tv;
+      time_cache.rows = (long)N * B;
+      time_cache.data = all;
+      time_cache.width = width;
+    }
+    auto sig = [&](float t) { return sqrtf((c * (powf(k, 2.f * t) - 1.f)) / (2.f * logf(k))); };
+    const std::vector<float> ts = sb_times(N, t_eps);
+    const float sig_T = sig(1.f);
+    float sig_p = sig(ts[0]), sigb_p = sqrtf(sig_T * sig_T - sig_p * sig_p + sbeps);
+    launch_repeat_sources(y, x, B, n, Dl, T, st);
+    const float* z = noise;
+    for (int i = 0; i < N; ++i) {
+      const float t = ts[i + 1];
+      const float sig_t = sig(t), sigb_t = sqrtf(sig_T * sig_T - sig_t * sig_t + sbeps);
+      float* est = score_tokens(x, tv + (long)i * B, y, B, T, st);
+      if (!ode) {
+        const float w_prev = sig_t * sig_t / (sig_p * sig_p + sbeps);
+        const float tmp = 1.f - sig_t * sig_t / (sig_p * sig_p + sbeps);
+        const float w_z = (i == N - 1) ? 0.f : sig_t * sqrtf(tmp);
+        launch_sb_update(x, est, z, w_prev, tmp, w_z, 0, B, n, Dl, T, st);
+        z += sz;
+      } else {
+        const float w_prev = sig_t * sigb_t / (sig_p * sigb_p + sbeps);
+        const float w_est = 1.f / (sig_T * sig_T + sbeps) * (sigb_t * sigb_t - sigb_p * sig_t * sigb_t / (sig_p + sbeps));
+        const float w_pm = 1.f / (sig_T * sig_T + sbeps) * (sig_t * sig_t - sig_p * sig_t * sigb_t / (sigb_p + sbeps));
+        launch_sb_update(x, est, y, w_prev, w_est, w_pm, 1, B, n, Dl, T, st);
+      }
+      sig_p = sig_t;
+      sigb_p = sigb_t;
+    }
+    return x;
+  }
+  // torch.linspace(1, eps, N + 1) in fp32 (symmetric fill), entries 0..N
+  static std::vector<float> sb_times(int N, float t_eps) {
+    std::vector<float> ts((size_t)N + 1);
+    const int steps = N + 1;
+    const float stp = (t_eps - 1.f) / (float)(steps - 1);
+    for (int i = 0; i < steps; ++i) ts[i] = i < steps / 2 ? 1.f + stp * (float)i : t_eps - stp * (float)(steps - 1 - i);
+    return ts;
+  }
+
   // ---------------------------------------------------------------- decoder
   int hop() const {
     int h = 1;
@@ -1696,6 +1829,97 @@ int dsn_pc_sample_sched(dsn_ctx* ctx, const float* y, const float* noise, uint64
   o.denoise = denoise;
   o.timesteps = timesteps_host;
   return dsn_pc_sample_ex(ctx, y, noise, seed, x_out, B, T, N, &o, nfe_out, stream);
+}
+
+int dsn_pc_sample_mix(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N,
+                      const dsn_mix_opts* opts, int* nfe_out, void* stream) {
+  return guarded(ctx, [&] {
+    if (!y || !x_out || !opts || B <= 0 || T <= 0 || N <= 0 || opts->corrector_steps < 0)
+      fail(DSN_EINVAL, "dsn_pc_sample_mix: bad arguments");
+    if (opts->predictor < 0 || opts->predictor > DSN_PRED_NONE || opts->corrector < 0 || opts->corrector > DSN_MIXCORR_NONE)
+      fail(DSN_EINVAL, "dsn_pc_sample_mix: unknown predictor %d / corrector %d", opts->predictor, opts->corrector);
+    const int n = ctx->cfg.n_src, Dl = ctx->cfg.latent_dim;
+    if (n > 4) fail(DSN_EINVAL, "dsn_pc_sample_mix: at most 4 sources");
+    if (!opts->prior_mix && n != 2)
+      fail(DSN_EINVAL, "MixSDE.prior_sampling is written for 2 sources (reference sdes.py:347); use PriorMixSDE");
+    if (opts->prior_mix && opts->avg_len < 1) fail(DSN_EINVAL, "PriorMixSDE: avg_len must be >= 1");
+    if (!(opts->sigma_max > opts->sigma_min) || !(opts->sigma_min > 0)) fail(DSN_EINVAL, "need 0 < sigma_min < sigma_max");
+    dsn_ctx::MixOpts o;
+    o.prior_mix = opts->prior_mix;
+    o.avg_len = opts->avg_len;
+    o.pred = opts->predictor;
+    o.corr = opts->corrector;
+    o.c = opts->corrector == DSN_MIXCORR_NONE ? 0 : opts->corrector_steps;
+    o.denoise = opts->denoise;
+    o.d_lambda = opts->d_lambda;
+    o.sigma_min = opts->sigma_min;
+    o.sigma_max = opts->sigma_max;
+    o.snr = opts->snr;
+    o.t_eps = opts->t_eps;
+    hipStream_t caller = (hipStream_t)stream;
+    const long ysz = (long)B * Dl * T, sz = ysz * n, draws = o.draws(N);
+    float* yb = ctx->wsbuf<float>("pc_y", ysz);
+    float* nz = ctx->wsbuf<float>("pc_noise", sz * draws);
+    ctx->upload_timesteps(B, N, o.t_eps, o.snr, caller);
+    hipStream_t st = ctx->enter(caller);
+    HIPCHK(hipMemcpyAsync(yb, y, sizeof(float) * ysz, hipMemcpyDeviceToDevice, st));
+    if (noise) HIPCHK(hipMemcpyAsync(nz, noise, sizeof(float) * sz * draws, hipMemcpyDeviceToDevice, st));
+    else launch_randn(nz, sz * draws, seed, 0, st);
+    char key[224];
+    snprintf(key, sizeof key, "pcmix:%d:%d:%d:%d:%d:%d:%d:%d:%a:%a:%a:%a:%a:%d", B, T, N, o.prior_mix, o.avg_len, o.pred,
+             o.corr, o.c, o.d_lambda, o.sigma_min, o.sigma_max, o.snr, o.t_eps, o.denoise);
+    float* res = nullptr;
+    ctx->run_graphed(key, st, [&](hipStream_t s2) { res = ctx->pc_sample_mix(yb, nz, B, T, N, o, s2); });
+    if (!res) res = ctx->wsbuf<float>(o.denoise ? "pc_xm" : "pc_x", sz);
+    HIPCHK(hipMemcpyAsync(x_out, res, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    ctx->leave(caller, st);
+    if (nfe_out) *nfe_out = N * (o.c + 1);
+    HIPCHK(hipGetLastError());
+  });
+}
+
+int dsn_sb_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N, float k,
+                  float c, float sb_eps, float t_eps, int sampler_type, void* stream) {
+  return guarded(ctx, [&] {
+    if (!y || !x_out || B <= 0 || T <= 0 || N <= 0) fail(DSN_EINVAL, "dsn_sb_sample: bad arguments");
+    if (sampler_type != DSN_SB_SDE && sampler_type != DSN_SB_ODE) fail(DSN_EINVAL, "Invalid type. Choose 'ode' or 'sde'.");
+    if (!(k > 0) || k == 1.f || !(c > 0)) fail(DSN_EINVAL, "SBVESDE: need k > 0, k != 1, c > 0");
+    const int n = ctx->cfg.n_src, Dl = ctx->cfg.latent_dim;
+    hipStream_t caller = (hipStream_t)stream;
+    const long ysz = (long)B * Dl * T, sz = ysz * n;
+    const long draws = sampler_type == DSN_SB_SDE ? N : 0;
+    float* yb = ctx->wsbuf<float>("pc_y", ysz);
+    float* nz = draws ? ctx->wsbuf<float>("pc_noise", sz * draws) : nullptr;
+    {  // step times t_1 .. t_N of linspace(1, eps, N + 1) as the network's time input
+      const std::vector<float> ts = dsn_ctx::sb_times(N, t_eps);
+      std::vector<float> ht((size_t)B * N);
+      for (int i = 0; i < N; ++i)
+        for (int b = 0; b < B; ++b) ht[(size_t)i * B + b] = ts[i + 1];
+      float* tv = ctx->wsbuf<float>("pc_t", (long)B * N);
+      if (!(ht == ctx->tv_host && ctx->tv_B == B)) {
+        HIPCHK(hipMemcpyAsync(tv, ht.data(), sizeof(float) * ht.size(), hipMemcpyHostToDevice, caller));
+        HIPCHK(hipStreamSynchronize(caller));
+        ctx->tv_host = ht;
+        ctx->tv_B = B;
+      }
+    }
+    hipStream_t st = ctx->enter(caller);
+    HIPCHK(hipMemcpyAsync(yb, y, sizeof(float) * ysz, hipMemcpyDeviceToDevice, st));
+    if (draws) {
+      if (noise) HIPCHK(hipMemcpyAsync(nz, noise, sizeof(float) * sz * draws, hipMemcpyDeviceToDevice, st));
+      else launch_randn(nz, sz * draws, seed, 0, st);
+    }
+    char key[160];
+    snprintf(key, sizeof key, "sb:%d:%d:%d:%a:%a:%a:%a:%d", B, T, N, k, c, sb_eps, t_eps, sampler_type);
+    float* res = nullptr;
+    ctx->run_graphed(key, st, [&](hipStream_t s2) {
+      res = ctx->sb_sample(yb, nz, B, T, N, k, c, sb_eps, t_eps, sampler_type == DSN_SB_ODE, s2);
+    });
+    if (!res) res = ctx->wsbuf<float>("pc_x", sz);
+    HIPCHK(hipMemcpyAsync(x_out, res, sizeof(float) * sz, hipMemcpyDeviceToDevice, st));
+    ctx->leave(caller, st);
+    HIPCHK(hipGetLastError());
+  });
 }
 
 int dsn_hop_length(const dsn_ctx* ctx) { return ctx ? ctx->hop() : DSN_EINVAL; }

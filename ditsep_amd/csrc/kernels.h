@@ -27,6 +27,23 @@ void launch_pc_item_norms(const float* a, long per_item, int B, float* out, hipS
 void launch_pc_predictor(float* x, float* x_mean, const float* y, const float* score_tok, const float* z,
                          float theta, float dt, float G, float g, int em, int B, int n, int D, int T, hipStream_t s);
 
+// ---- secondary sampler family (MixSDE / PriorMixSDE + ald2, Schroedinger bridge) on x [B,n,D,T] ----
+// smix [B][D*T] = PriorMixSDE._std_sigma_mix of the flattened mixture latent (null: MixSDE, factor 1)
+void launch_sigma_mix(const float* y, float* smix, int B, int L, int avg_len, hipStream_t s);
+// x = 0.5 y + (s1 A + s2 Pn) z * smix
+void launch_mix_prior(const float* y, const float* z, float* x, const float* smix, float s1, float s2, int B, int n, int D,
+                      int T, hipStream_t s);
+// ald2 step with L = (sq1 A + sq2 Pn) smix (x_mean may be null)
+void launch_mix_corrector(float* x, float* x_mean, const float* score_tok, const float* z, const float* smix, float sq1,
+                          float sq2, float snr, int B, int n, int D, int T, hipStream_t s);
+// em = 0 reverse diffusion, 1 Euler-Maruyama; g = diffusion scalar, sqdt = sqrt(dt)
+void launch_mix_predictor(float* x, float* x_mean, const float* score_tok, const float* z, const float* smix,
+                          float lambda, float dt, float g, float sqdt, int em, int B, int n, int D, int T, hipStream_t s);
+// x = w_prev x + w_est est + w3 (third_is_y ? y[B,1,D,T] : z[B,n,D,T]); third may be null
+void launch_sb_update(float* x, const float* est_tok, const float* third, float w_prev, float w_est, float w3,
+                      int third_is_y, int B, int n, int D, int T, hipStream_t s);
+void launch_repeat_sources(const float* y, float* x, int B, int n, int D, int T, hipStream_t s);
+
 // ---- DiT pieces ---------------------------------------------------------------
 // x += bias + sum(split-K slabs) (written back when nslab > 0), then LayerNorm (do_norm) or a
 // plain copy to operand planes.  D <= 4096, D % 4 == 0.

@@ -174,6 +174,131 @@ __global__ void pc_predictor_kernel(float* __restrict__ x, float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ secondary sampler family on the latent state
+// MixSDE / PriorMixSDE (+ the ald2 corrector) and the Schroedinger-bridge sampler of the reference's sdes package
+// (src/sdes/sdes.py:182-593,701-779, correctors.py:87-121, __init__.py:284-389), on x [B,n,D,T] read as [B,n,D*T].
+// With A = 11^T/n and Pn = I - A every matrix of these SDEs is a*A + p*Pn:  (aA + pPn) v = a*mean_src(v) +
+// p*(v - mean_src(v)).  One thread per (b, d, t) position walks the n <= 4 sources; smix [B][D*T] is PriorMixSDE's
+// running RMS of the mixture (null = 1).
+__global__ void sigma_mix_kernel(const float* __restrict__ y, float* __restrict__ smix, int L, int avg_len, long total) {
+  // 0.5 * sqrt(clamp(avg_pool1d(y^2, avg_len, stride 1, zero padding avg_len/2, count_include_pad), 1e-4))
+  const int pad = avg_len / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / L;
+    const int l = (int)(i - b * L);
+    float acc = 0.f;
+    for (int k = 0; k < avg_len; ++k) {
+      const int j = l - pad + k;
+      if (j >= 0 && j < L) {
+        const float v = y[b * L + j];
+        acc += v * v;
+      }
+    }
+    smix[i] = 0.5f * sqrtf(fmaxf(acc / (float)avg_len, 1e-4f));
+  }
+}
+
+__global__ void mix_prior_kernel(const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ x,
+                                 const float* __restrict__ smix, float s1, float s2, int n, int D, int T, long npos) {
+  const long DT = (long)D * T;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npos; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / DT, l = p - b * DT;
+    const float sm = smix ? smix[p] : 1.f;
+    float mz = 0.f;
+    for (int s = 0; s < n; ++s) mz += z[(b * n + s) * DT + l];
+    mz /= (float)n;
+    const float mean = 0.5f * y[p];
+    for (int s = 0; s < n; ++s) {
+      const long i = (b * n + s) * DT + l;
+      x[i] = mean + (s1 * sm) * mz + (s2 * sm) * (z[i] - mz);
+    }
+  }
+}
+
+// ald2: grad = L L score, x_mean = x + 2 snr^2 grad, x = x_mean + 2 snr L z with L = sqrt(ev1) A + sqrt(ev2) Pn (x smix)
+__global__ void mix_corrector_kernel(float* __restrict__ x, float* __restrict__ xmean, const float* __restrict__ sc,
+                                     const float* __restrict__ z, const float* __restrict__ smix, float sq1, float sq2,
+                                     float snr, int n, int D, int T, long npos) {
+  const long DT = (long)D * T;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npos; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / DT, l = p - b * DT;
+    const int c = (int)(l / T), t = (int)(l - (long)c * T);
+    const float sm = smix ? smix[p] : 1.f;
+    const float a1 = sq1 * sm, a2 = sq2 * sm;
+    float sv[4], zv[4], ms = 0.f, mz = 0.f;
+    for (int s = 0; s < n; ++s) {
+      sv[s] = sc[(b * T + t) * ((long)n * D) + (long)s * D + c];
+      zv[s] = z[(b * n + s) * DT + l];
+      ms += sv[s];
+      mz += zv[s];
+    }
+    ms /= (float)n;
+    mz /= (float)n;
+    // first L: u = a1 ms + a2 (s - ms); its source mean is a1 ms; second L: a1 (a1 ms) + a2 (u - a1 ms)
+    for (int s = 0; s < n; ++s) {
+      const long i = (b * n + s) * DT + l;
+      const float u = a1 * ms + a2 * (sv[s] - ms);
+      const float grad = a1 * (a1 * ms) + a2 * (u - a1 * ms);
+      const float xm = x[i] + 2.f * snr * snr * grad;
+      if (xmean) xmean[i] = xm;
+      x[i] = xm + (2.f * snr * a1) * mz + (2.f * snr * a2) * (zv[s] - mz);
+    }
+  }
+}
+
+// reverse diffusion (em = 0): x_mean = x + lambda dt (x - m) + G^2 s, x = x_mean + G z with G = g sqrt(dt) smix;
+// Euler-Maruyama (em = 1): x_mean = x + (lambda (x - m) + (g smix)^2 s) dt, x = x_mean + g smix sqrt(dt) z
+__global__ void mix_predictor_kernel(float* __restrict__ x, float* __restrict__ xmean, const float* __restrict__ sc,
+                                     const float* __restrict__ z, const float* __restrict__ smix, float lambda, float dt,
+                                     float g, float sqdt, int em, int n, int D, int T, long npos) {
+  const long DT = (long)D * T;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npos; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / DT, l = p - b * DT;
+    const int c = (int)(l / T), t = (int)(l - (long)c * T);
+    const float sm = smix ? smix[p] : 1.f;
+    float xv[4], mx = 0.f;
+    for (int s = 0; s < n; ++s) {
+      xv[s] = x[(b * n + s) * DT + l];
+      mx += xv[s];
+    }
+    mx /= (float)n;
+    const float gs = g * sm;
+    for (int s = 0; s < n; ++s) {
+      const long i = (b * n + s) * DT + l;
+      const float scv = sc[(b * T + t) * ((long)n * D) + (long)s * D + c];
+      float xm, xn;
+      if (em) {
+        const float total = -lambda * (xv[s] - mx) - gs * gs * scv;
+        xm = xv[s] + total * (-dt);
+        xn = xm + gs * sqdt * z[i];
+      } else {
+        const float f = -lambda * (xv[s] - mx) * dt;
+        const float G = gs * sqdt;
+        const float rev = f - G * G * scv;
+        xm = xv[s] - rev;
+        xn = xm + G * z[i];
+      }
+      xmean[i] = xm;
+      x[i] = xn;
+    }
+  }
+}
+
+// Schroedinger-bridge step: x = w_prev x + w_est est + w3 * (third_is_y ? y : z)      (est token-major)
+__global__ void sb_update_kernel(float* __restrict__ x, const float* __restrict__ est, const float* __restrict__ third,
+                                 float w_prev, float w_est, float w3, int third_is_y, int n, int D, int T, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const PcIdx ix = pc_index(i, n, D, T);
+    const float th = third ? third[third_is_y ? ix.yi : i] : 0.f;
+    x[i] = w_prev * x[i] + w_est * est[ix.si] + w3 * th;
+  }
+}
+// x[b, s] = y[b, 0] for every source s   (xt = y.repeat(1, n, 1, 1))
+__global__ void repeat_sources_kernel(const float* __restrict__ y, float* __restrict__ x, int n, int D, int T, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    x[i] = y[pc_index(i, n, D, T).yi];
+}
+
 // ------------------------------------------------------------------ LayerNorm
 // Residual-stream update fused with the next LayerNorm: x[row] += bias + sum of the split-K
 // partial slabs of the preceding GEMM (written back when any were added), then LayerNorm
@@ -718,6 +843,37 @@ void launch_pc_predictor(float* x, float* xm, const float* y, const float* sc, c
   const long total = (long)B * n * D * T;
   hipLaunchKernelGGL(pc_predictor_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, xm, y, sc, z, theta, dt, G, g,
                      em, n, D, T, total);
+}
+void launch_sigma_mix(const float* y, float* smix, int B, int L, int avg_len, hipStream_t st) {
+  const long total = (long)B * L;
+  hipLaunchKernelGGL(sigma_mix_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, y, smix, L, avg_len, total);
+}
+void launch_mix_prior(const float* y, const float* z, float* x, const float* smix, float s1, float s2, int B, int n, int D,
+                      int T, hipStream_t st) {
+  const long npos = (long)B * D * T;
+  hipLaunchKernelGGL(mix_prior_kernel, dim3(grid_for(npos)), dim3(TPB), 0, st, y, z, x, smix, s1, s2, n, D, T, npos);
+}
+void launch_mix_corrector(float* x, float* xm, const float* sc, const float* z, const float* smix, float sq1, float sq2,
+                          float snr, int B, int n, int D, int T, hipStream_t st) {
+  const long npos = (long)B * D * T;
+  hipLaunchKernelGGL(mix_corrector_kernel, dim3(grid_for(npos)), dim3(TPB), 0, st, x, xm, sc, z, smix, sq1, sq2, snr, n,
+                     D, T, npos);
+}
+void launch_mix_predictor(float* x, float* xm, const float* sc, const float* z, const float* smix, float lambda, float dt,
+                          float g, float sqdt, int em, int B, int n, int D, int T, hipStream_t st) {
+  const long npos = (long)B * D * T;
+  hipLaunchKernelGGL(mix_predictor_kernel, dim3(grid_for(npos)), dim3(TPB), 0, st, x, xm, sc, z, smix, lambda, dt, g,
+                     sqdt, em, n, D, T, npos);
+}
+void launch_sb_update(float* x, const float* est, const float* third, float w_prev, float w_est, float w3, int third_is_y,
+                      int B, int n, int D, int T, hipStream_t st) {
+  const long total = (long)B * n * D * T;
+  hipLaunchKernelGGL(sb_update_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, x, est, third, w_prev, w_est, w3,
+                     third_is_y, n, D, T, total);
+}
+void launch_repeat_sources(const float* y, float* x, int B, int n, int D, int T, hipStream_t st) {
+  const long total = (long)B * n * D * T;
+  hipLaunchKernelGGL(repeat_sources_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, y, x, n, D, T, total);
 }
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,

@@ -25,7 +25,7 @@ MAX_VAE_BLOCKS = 8
 
 EXPORTS = [
     "dsn_create", "dsn_destroy", "dsn_last_error", "dsn_load_tensor", "dsn_finalize_weights", "dsn_finalize_weights_ex",
-    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_decode",
+    "dsn_score", "dsn_ouve_schedule", "dsn_pc_sample", "dsn_pc_sample_sched", "dsn_pc_sample_ex", "dsn_pc_sample_mix", "dsn_sb_sample", "dsn_decode",
     "dsn_encode", "dsn_decode_chunked", "dsn_encode_chunked",
     "dsn_latent_frames", "dsn_hop_length", "dsn_separate", "dsn_enable_graphs",
     "dsn_workspace_bytes", "dsn_profile_begin", "dsn_profile_end", "dsn_profile_hbm", "dsn_profile_rows", "dsn_test_igemm",
@@ -43,6 +43,18 @@ class DsnSamplerOpts(C.Structure):
         ("snr", C.c_float), ("t_eps", C.c_float), ("denoise", C.c_int),
         ("timesteps", C.POINTER(C.c_float)), ("prior_mean", C.c_void_p), ("intermediates", C.c_void_p),
     ]
+
+
+class DsnMixOpts(C.Structure):
+    _fields_ = [
+        ("prior_mix", C.c_int), ("d_lambda", C.c_float), ("sigma_min", C.c_float), ("sigma_max", C.c_float),
+        ("avg_len", C.c_int), ("predictor", C.c_int), ("corrector", C.c_int), ("corrector_steps", C.c_int),
+        ("snr", C.c_float), ("t_eps", C.c_float), ("denoise", C.c_int),
+    ]
+
+
+MIX_CORRECTORS = {"ald2": 0, "none": 1}
+SB_TYPES = {"sde": 0, "ode": 1}
 
 
 class DsnConfig(C.Structure):
@@ -90,6 +102,8 @@ def load_library() -> C.CDLL:
     lib.dsn_pc_sample_sched.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, fp, ci, cf, ci, C.POINTER(ci), vp]
     lib.dsn_pc_sample_ex.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, C.POINTER(DsnSamplerOpts),
                                      C.POINTER(ci), vp]
+    lib.dsn_pc_sample_mix.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, C.POINTER(DsnMixOpts), C.POINTER(ci), vp]
+    lib.dsn_sb_sample.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp]
     lib.dsn_decode.argtypes = [vp, vp, vp, ci, ci, ci, vp]
     lib.dsn_encode.argtypes = [vp, vp, vp, C.c_uint64, vp, ci, ci, vp]
     lib.dsn_decode_chunked.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
@@ -256,6 +270,42 @@ class Engine:
         if intermediate:
             return x, nfe.value, [(im[i, 0], im[i, 1]) for i in range(N)]
         return x, nfe.value
+
+    def pc_sample_mix(self, y, noise=None, *, N=30, prior_mix=False, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5,
+                      avg_len=510, predictor="reverse_diffusion", corrector="ald2", corrector_steps=1, snr=0.5,
+                      t_eps=0.03, denoise=True, seed=0):
+        """MixSDE / PriorMixSDE predictor-corrector sampler (ald2 corrector) on the latent state."""
+        if predictor not in PREDICTORS or corrector not in MIX_CORRECTORS:
+            raise NotImplementedError(f"no native kernel for predictor {predictor!r} / corrector {corrector!r} with MixSDE")
+        y = _dev32(y, self.device)
+        B, _, D, T = y.shape
+        c = 0 if corrector == "none" else int(corrector_steps)
+        draws = 1 + N * (c + (0 if predictor == "none" else 1))
+        if noise is not None:
+            noise = _dev32(noise, self.device)
+            assert tuple(noise.shape) == (draws, B, self.n_src, D, T), noise.shape
+        x = torch.empty((B, self.n_src, D, T), device=self.device, dtype=torch.float32)
+        o = DsnMixOpts(int(prior_mix), float(d_lambda), float(sigma_min), float(sigma_max), int(avg_len),
+                       PREDICTORS[predictor], MIX_CORRECTORS[corrector], c, float(snr), float(t_eps), int(denoise))
+        nfe = C.c_int()
+        self._check(self.lib.dsn_pc_sample_mix(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N, C.byref(o),
+                                               C.byref(nfe), self._stream()), "dsn_pc_sample_mix")
+        return x, nfe.value
+
+    def sb_sample(self, y, noise=None, *, N=50, k=2.6, c=0.4, sb_eps=1e-8, t_eps=1e-4, sampler_type="ode", seed=0):
+        """Schroedinger-bridge sampler (reference get_sb_sampler + SBVESDE) on the latent state."""
+        if sampler_type not in SB_TYPES:
+            raise ValueError("Invalid type. Choose 'ode' or 'sde'.")
+        y = _dev32(y, self.device)
+        B, _, D, T = y.shape
+        if noise is not None:
+            noise = _dev32(noise, self.device)
+            assert tuple(noise.shape) == (N, B, self.n_src, D, T), noise.shape
+        x = torch.empty((B, self.n_src, D, T), device=self.device, dtype=torch.float32)
+        self._check(self.lib.dsn_sb_sample(self.ctx, _ptr(y), _ptr(noise), seed, _ptr(x), B, T, N, float(k), float(c),
+                                           float(sb_eps), float(t_eps), SB_TYPES[sampler_type], self._stream()),
+                    "dsn_sb_sample")
+        return x
 
     def decode(self, est, target_len: Optional[int] = None, chunked: bool = False, overlap: int = 32,
                chunk_size: int = 128):

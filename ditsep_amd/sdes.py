@@ -57,6 +57,51 @@ class OUVESDE:
         return self._mean(x0, t, y), self._std(t)
 
 
+class _MixBase:
+    """Parameter carrier of the source-mixing VE SDEs (reference src/sdes/sdes.py:182-593): drift -lambda Pn x with
+    Pn = I - 11^T/n, diffusion sigma_min (sigma_max/sigma_min)^t sqrt(2 log ratio).  The reference writes them for
+    time-domain tensors [B, n, L]; the native sampler runs their arithmetic on the latent state read as
+    [B, n, D*T]."""
+    prior_mix = False
+
+    def __init__(self, ndim, d_lambda, sigma_min, sigma_max, N=1000, avg_len=510, **ignored_kwargs):
+        self.ndim, self.d_lambda = int(ndim), float(d_lambda)
+        self.sigma_min, self.sigma_max, self.N, self.avg_len = float(sigma_min), float(sigma_max), int(N), int(avg_len)
+
+    @property
+    def T(self):
+        return 1.0
+
+    def copy(self):
+        return type(self)(self.ndim, self.d_lambda, self.sigma_min, self.sigma_max, N=self.N, avg_len=self.avg_len)
+
+
+@SDERegistry.register("mix")
+class MixSDE(_MixBase):
+    """reference src/sdes/sdes.py:182-352 (its prior is written for 2 sources)."""
+
+
+@SDERegistry.register("priormix")
+class PriorMixSDE(_MixBase):
+    """reference src/sdes/sdes.py:355-593: diffusion scaled by the running RMS (window avg_len) of the mixture."""
+    prior_mix = True
+
+
+@SDERegistry.register("sbve")
+class SBVESDE:
+    """Schroedinger bridge with a variance-exploding reference process (reference src/sdes/sdes.py:701-779)."""
+
+    def __init__(self, k, c, N=50, eps=1e-8, sampler_type="ode", **ignored_kwargs):
+        self.k, self.c, self.N, self.eps, self.sampler_type = float(k), float(c), int(N), float(eps), sampler_type
+
+    @property
+    def T(self):
+        return 1
+
+    def copy(self):
+        return SBVESDE(self.k, self.c, N=self.N)
+
+
 @PredictorRegistry.register("reverse_diffusion")
 class ReverseDiffusionPredictor:
     """Marker: executed natively (reference src/sdes/predictors.py:55-66)."""
@@ -85,7 +130,8 @@ class LangevinCorrector:
 
 @CorrectorRegistry.register("ald2")
 class AnnealedLangevinDynamics2:
-    """Registered name only: needs MixSDE / PriorMixSDE (correctors.py:93-96), which are outside this path."""
+    """Marker: executed natively with MixSDE / PriorMixSDE (reference src/sdes/correctors.py:87-121); any other SDE
+    raises NotImplementedError, as the reference does (:93-96)."""
 
 
 @CorrectorRegistry.register("none")
@@ -107,11 +153,30 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
     if engine is None:
         raise NotImplementedError("get_pc_sampler needs a native score model (object with `.engine`); "
                                   "arbitrary Python score functions are not supported (no PyTorch fallback)")
+    if isinstance(sde, _MixBase):
+        if corrector_name not in ("ald2", "none"):
+            raise NotImplementedError(f"corrector '{corrector_name}' with {type(sde).__name__}: the native sampler "
+                                      "runs ald2 (or none) there")
+        if true_mean is not None or intermediate:
+            raise NotImplementedError("true_mean / intermediate are implemented for the OUVE SDE only")
+        if sde.ndim != engine.n_src or n_spkrs != engine.n_src:
+            raise ValueError(f"sde.ndim={sde.ndim} / n_spkrs={n_spkrs} but the engine was built for {engine.n_src} sources")
+        mix_counter = {"calls": 0}
+
+        def mix_sampler():
+            s = seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,)).item()) + mix_counter["calls"]
+            mix_counter["calls"] += 1
+            return engine.pc_sample_mix(y, noise, N=sde.N, prior_mix=sde.prior_mix, d_lambda=sde.d_lambda,
+                                        sigma_min=sde.sigma_min, sigma_max=sde.sigma_max, avg_len=sde.avg_len,
+                                        predictor=predictor_name, corrector=corrector_name,
+                                        corrector_steps=int(corrector_steps), snr=float(snr), t_eps=float(eps),
+                                        denoise=bool(denoise), seed=s)
+
+        return mix_sampler
     if corrector_name == "ald2":
-        raise NotImplementedError("ald2 needs MixSDE / PriorMixSDE (reference correctors.py:93-96); the native "
-                                  "sampler implements the OUVE SDE")
+        raise NotImplementedError(f"SDE class {type(sde).__name__} not yet supported.")     # reference correctors.py:93-96
     if not isinstance(sde, OUVESDE):
-        raise NotImplementedError("native sampler implements the OUVE SDE")
+        raise NotImplementedError("the native PC sampler implements OUVESDE, MixSDE and PriorMixSDE")
     # probability_flow: accepted and without effect, as in the reference -- Predictor.__init__ keeps the flag but
     # builds its reverse SDE with sde.reverse(score_fn) (predictors.py:13-18), so the ODE branch is never reached.
     if n_spkrs != engine.n_src:
@@ -133,6 +198,30 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
                                 corrector=corr, prior_mean=true_mean, intermediate=bool(intermediate))
 
     return pc_sampler
+
+
+def get_sb_sampler(sde, model, y, eps=1e-4, n_steps=50, sampler_type="ode", pad_dim=None, noise=None, seed=None,
+                   **kwargs):
+    """Reference signature (src/sdes/__init__.py:284-389).  `model` must be a native-backed model (`.engine`); its
+    output is taken as the data estimate.  Returns a closure -> (x [B,n,D,T], n_steps): like the reference, the second
+    value is the `n_steps` ARGUMENT, the number of steps taken is sde.N."""
+    if not isinstance(sde, SBVESDE):
+        raise NotImplementedError("get_sb_sampler needs an SBVESDE")
+    engine = getattr(model, "engine", None)
+    if engine is None:
+        raise NotImplementedError("get_sb_sampler needs a native model (object with `.engine`); no PyTorch fallback")
+    if sampler_type not in ("sde", "ode"):
+        raise ValueError("Invalid type. Choose 'ode' or 'sde'.")
+    counter = {"calls": 0}
+
+    def sampler():
+        s = seed if seed is not None else int(torch.randint(0, 2**31 - 1, (1,)).item()) + counter["calls"]
+        counter["calls"] += 1
+        x = engine.sb_sample(y, noise, N=sde.N, k=sde.k, c=sde.c, sb_eps=sde.eps, t_eps=float(eps),
+                             sampler_type=sampler_type, seed=s)
+        return x, n_steps
+
+    return sampler
 
 
 def schedule_timesteps(schedule: str, T: float, eps: float, N: int) -> torch.Tensor:

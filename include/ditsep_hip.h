@@ -137,6 +137,32 @@ typedef struct dsn_sampler_opts {
 int dsn_pc_sample_ex(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T,
                      int N, const dsn_sampler_opts* opts, int* nfe_out, void* stream);
 
+/* The secondary SDE family of the reference's sampler package on the latent state read as [B, n_src, D*T]:
+ * MixSDE (sdes.py:182-352) / PriorMixSDE (:355-593; diffusion scaled by the running RMS of the mixture over `avg_len`
+ * flattened latent samples) through the same predictor-corrector loop, predictors as above, corrector
+ * DSN_MIXCORR_ALD2 (AnnealedLangevinDynamics2, correctors.py:87-121) or DSN_MIXCORR_NONE.  noise: [1 + N*(corrector_steps
+ * + (predictor != NONE)), B, n_src, D, T] in consumption order, or NULL (device RNG).  MixSDE's prior is written for
+ * 2 sources (reference :347).  nfe_out = N*(corrector_steps+1). */
+enum { DSN_MIXCORR_ALD2 = 0, DSN_MIXCORR_NONE = 1 };
+typedef struct dsn_mix_opts {
+  int prior_mix;                      /* 0 MixSDE, 1 PriorMixSDE */
+  float d_lambda, sigma_min, sigma_max;
+  int avg_len;                        /* PriorMixSDE only */
+  int predictor, corrector, corrector_steps;
+  float snr, t_eps;
+  int denoise;
+} dsn_mix_opts;
+int dsn_pc_sample_mix(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N,
+                      const dsn_mix_opts* opts, int* nfe_out, void* stream);
+
+/* get_sb_sampler (src/sdes/__init__.py:284-389) with SBVESDE(k, c, eps = sb_eps) (sdes.py:701-779): the state starts
+ * as y repeated over the sources; N first-order Schroedinger-bridge steps over linspace(1, t_eps, N + 1), the score
+ * network's output taken as the data estimate.  sampler_type DSN_SB_SDE consumes noise [N, B, n_src, D, T] (or the
+ * device RNG), DSN_SB_ODE none. */
+enum { DSN_SB_SDE = 0, DSN_SB_ODE = 1 };
+int dsn_sb_sample(dsn_ctx* ctx, const float* y, const float* noise, uint64_t seed, float* x_out, int B, int T, int N, float k,
+                  float c, float sb_eps, float t_eps, int sampler_type, void* stream);
+
 /* LatentDiffSep.decode: est [B,n_src,D,T] -> wav [B,n_src,target_len] (crop of hop*T;
  * target_len <= 0 means hop*T). */
 int dsn_decode(dsn_ctx* ctx, const float* est, float* wav, int B, int T, int target_len, void* stream);

@@ -234,6 +234,73 @@ def gen_e2e(ns, channels=8, tag="tiny"):
          wsum_vae=checksum(vsd), wsum_dit=checksum(dsd), channels=channels)
 
 
+def toy_score3(x, t, y):
+    """Closed-form stand-in score for the flattened-latent sampler fixtures (x [B, n, L], y [B, 1, L])."""
+    tt = t.reshape(-1, 1, 1)
+    return -(x - 0.5 * y) * 0.05 / (1 + tt) + 0.01 * torch.tanh(x)
+
+
+MIX_VARIANTS = (  # (sde kind, predictor, corrector, corrector_steps)
+    ("mix", "reverse_diffusion", "ald2", 1), ("mix", "euler_maruyama", "ald2", 2), ("mix", "none", "ald2", 1),
+    ("priormix", "reverse_diffusion", "ald2", 1), ("priormix", "euler_maruyama", "ald2", 1),
+)
+
+
+def gen_sampler_mix(ns):
+    """MixSDE / PriorMixSDE with the ald2 corrector through the reference's get_pc_sampler, on latents flattened to
+    [B, 1, D*T] (the 3-D layout these classes are written for): sdes.py:182-593, correctors.py:87-121."""
+    import sdes.sdes as S
+    B, D, T, N = 2, 64, 8, 6
+    g = torch.Generator().manual_seed(200)
+    y4 = torch.randn((B, 1, D, T), generator=g)
+    yf = y4.reshape(B, 1, D * T)
+    out = {"y": y4, "N": N, "eps": 0.03, "snr": 0.5, "seed": 7, "d_lambda": 2.0, "sigma_min": 0.05, "sigma_max": 0.5,
+           "avg_len": 50}
+    for kind, pred, corr, c in MIX_VARIANTS:
+        sde = (S.MixSDE(2, 2.0, 0.05, 0.5, N=N) if kind == "mix"
+               else S.PriorMixSDE(2, 2.0, 0.05, 0.5, N=N, avg_len=50))
+        for dn in (True, False):
+            torch.manual_seed(7)
+            smp = ns.sdes.get_pc_sampler(pred, corr, sde=sde, score_fn=toy_score3, y=yf, eps=0.03, snr=0.5,
+                                         corrector_steps=c, denoise=dn, n_spkrs=2)
+            x, nfe = smp()
+            key = f"{kind}_{pred}_{corr}_c{c}_dn{int(dn)}"
+            out["x_" + key] = x.reshape(B, 2, D, T)
+            out["nfe_" + key] = nfe
+    # PriorMixSDE with 3 sources and an even / odd averaging window
+    for avg_len in (7, 8):
+        sde = S.PriorMixSDE(3, 1.5, 0.05, 0.5, N=N, avg_len=avg_len)
+        torch.manual_seed(8)
+        smp = ns.sdes.get_pc_sampler("reverse_diffusion", "ald2", sde=sde, score_fn=toy_score3, y=yf, eps=0.03,
+                                     snr=0.5, corrector_steps=1, denoise=True, n_spkrs=3)
+        x, _ = smp()
+        out[f"x_priormix3_avg{avg_len}"] = x.reshape(B, 3, D, T)
+    save("sampler_mix", **out)
+
+
+def gen_sampler_sb(ns):
+    """get_sb_sampler (sde and ode types) with SBVESDE on flattened latents (sdes.py:701-779, __init__.py:284-389);
+    `model` = a closed-form data estimate."""
+    import sdes.sdes as S
+    B, D, T, N = 2, 64, 8, 5
+    g = torch.Generator().manual_seed(210)
+    y4 = torch.randn((B, 1, D, T), generator=g)
+    yf = y4.reshape(B, 1, D * T)
+
+    def model(x, t, y):
+        return 0.7 * x + 0.2 * y + 0.05 * torch.tanh(x) * t.reshape(-1, 1, 1)
+
+    out = {"y": y4, "N": N, "eps": 1e-4, "seed": 9, "k": 2.6, "c": 0.4}
+    for st in ("sde", "ode"):
+        sde = S.SBVESDE(2.6, 0.4, N=N)
+        torch.manual_seed(9)
+        x, ns_ = ns.sdes.get_sb_sampler(sde, model, yf, eps=1e-4, n_steps=17, sampler_type=st,
+                                        pad_dim=(slice(None), None, None))()
+        out["x_" + st] = x.reshape(B, 2, D, T)
+        out["n_steps_" + st] = ns_
+    save("sampler_sb", **out)
+
+
 def gen_state_keys(ns):
     """state_dict key order and parameters() order of the reference modules a checkpoint of this path holds
     (DiffusionTransformer incl. its LayerNorm `beta` / rotary `inv_freq` BUFFERS, Oobleck encoder / decoder with
@@ -285,6 +352,8 @@ def main():
     gen_sde_tables(ns)
     gen_sampler_toy(ns)
     gen_sampler_variants(ns)
+    gen_sampler_mix(ns)
+    gen_sampler_sb(ns)
     gen_dit(ns)
     gen_vae(ns)
     gen_vae(ns, channels=32, tag="c32")

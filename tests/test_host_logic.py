@@ -31,7 +31,8 @@ def test_registered_names_match_reference():
     # reference src/sdes/predictors.py:39,55,69 and correctors.py:35,58,87,124
     assert set(sdes.PredictorRegistry.get_all_names()) == {"euler_maruyama", "reverse_diffusion", "none"}
     assert set(sdes.CorrectorRegistry.get_all_names()) == {"langevin", "ald", "ald2", "none"}
-    assert "ouve" in sdes.SDERegistry.get_all_names()
+    # reference src/sdes/sdes.py:182,355,595,701
+    assert set(sdes.SDERegistry.get_all_names()) == {"ouve", "mix", "priormix", "sbve"}
 
 
 def test_ouve_closed_forms_match_reference_tables(golden):

@@ -182,3 +182,72 @@ def test_vae_chunk_plan_edges():
     assert covered[0] == 0 and covered[-1] == 44 and set(covered) == set(range(45))
     with pytest.raises(ValueError):
         ovae.chunk_plan(10, 16, 4)                                             # shorter than one chunk
+
+
+# ------------------------------------------------------------------ secondary sampler family on flattened latents
+def _toy_score4(x, t, y):
+    tt = t.reshape(-1, 1, 1, 1)
+    return -(x - 0.5 * y) * 0.05 / (1 + tt) + 0.01 * torch.tanh(x)
+
+
+def _priormix_noise(seed, draws, B, n, D, Tn):
+    """The seeded draws as the REFERENCE's PriorMixSDE loop consumes them.  Its state comes out of
+    einsum("bcdt,bdt->bct") laid out source-fastest in memory ([B, L, n] strides), and every later `randn_like(x)`
+    inherits those strides: torch then fills the tensor through its non-contiguous normal_ path (memory order, scalar
+    sampler) instead of the vectorised contiguous one -- a different value sequence from the same generator state.
+    (The prior's own draw is randn_like of an expanded tensor: plain contiguous.)  The oracle and the native path
+    take noise in the logical [B, n, D, T] layout; only this fixture comparison needs the emulation."""
+    g = torch.Generator().manual_seed(seed)
+    L = D * Tn
+    out = [torch.randn((B, n, L), generator=g)]
+    for _ in range(draws - 1):
+        out.append(torch.empty_strided((B, n, L), (n * L, 1, n)).normal_(generator=g).contiguous())
+    return torch.stack(out).reshape(draws, B, n, D, Tn)
+
+
+def test_mix_sde_samplers_vs_reference(golden):
+    """MixSDE / PriorMixSDE + ald2 through the reference's get_pc_sampler (on latents flattened to [B,1,D*T]) vs the
+    oracle's source-mean restatement, same seeded noise stream."""
+    from oracle import sampler_variants as sv
+    from oracle.make_golden import MIX_VARIANTS
+
+    g = golden("sampler_mix")
+    y = T(g["y"])
+    B, _, D, Tn = y.shape
+    N = int(g["N"])
+    for kind, pred, corr, c in MIX_VARIANTS:
+        sde = sv.MixSDE(2, float(g["d_lambda"]), float(g["sigma_min"]), float(g["sigma_max"]), N=N,
+                        prior_mix=(kind == "priormix"), avg_len=int(g["avg_len"]))
+        for dn in (True, False):
+            draws = sv.mix_noise_draws(N, c, pred)
+            noise = (_priormix_noise(int(g["seed"]), draws, B, 2, D, Tn) if kind == "priormix"
+                     else sampler.draw_noise(int(g["seed"]), draws, (B, 2, D, Tn)))
+            x, nfe = sv.pc_sample_mix(_toy_score4, y, noise, sde, predictor=pred, corrector=corr, eps=float(g["eps"]),
+                                      snr=float(g["snr"]), corrector_steps=c, denoise=dn)
+            key = f"{kind}_{pred}_{corr}_c{c}_dn{int(dn)}"
+            assert nfe == int(g["nfe_" + key])
+            close(x, g["x_" + key], 2e-5)
+    for avg_len in (7, 8):
+        sde = sv.MixSDE(3, 1.5, 0.05, 0.5, N=N, prior_mix=True, avg_len=avg_len)
+        noise = _priormix_noise(8, sv.mix_noise_draws(N, 1, "reverse_diffusion"), B, 3, D, Tn)
+        x, _ = sv.pc_sample_mix(_toy_score4, y, noise, sde, eps=0.03, snr=0.5, corrector_steps=1)
+        close(x, g[f"x_priormix3_avg{avg_len}"], 2e-5)
+
+
+def test_sb_sampler_vs_reference(golden):
+    from oracle import sampler_variants as sv
+
+    g = golden("sampler_sb")
+    y = T(g["y"])
+    B, _, D, Tn = y.shape
+    N = int(g["N"])
+
+    def model(x, t, yy):
+        return 0.7 * x + 0.2 * yy + 0.05 * torch.tanh(x) * t.reshape(-1, 1, 1, 1)
+
+    for st in ("sde", "ode"):
+        noise = sampler.draw_noise(int(g["seed"]), N, (B, 2, D, Tn))
+        x, ns = sv.sb_sample(model, y, noise, sv.SBVE(float(g["k"]), float(g["c"]), N=N), eps=float(g["eps"]),
+                             sampler_type=st, n_steps=17)
+        assert ns == int(g["n_steps_" + st]) == 17
+        close(x, g["x_" + st], 2e-5)
