@@ -226,6 +226,182 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void lab_kernel(const Prob d, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong structure: 8 waves = 2 wave rows x 4 wave columns; the wave rows are the two SIMD partners (waves w and
+// w + 4 share a SIMD) and alternate roles every barrier interval: one group issues its whole k-tile of MFMAs from
+// fragments already in registers while the other fetches its next k-tile's fragments from LDS (and everyone issues
+// its share of the global->LDS prefetch), so the matrix pipe of every SIMD always has a wave feeding it and no MFMA
+// waits on an LDS read.  BK = 32 k-tiles in a ring of NST slots, NST - 1 tiles in flight behind counted vmcnt.
+//   interval 2T   : group 0 MFMA(T)              | group 1 reads fragments(T)
+//   interval 2T+1 : group 0 reads fragments(T+1) | group 1 MFMA(T)            (all waves: issue tile T + NST)
+// Tile T is read from LDS in intervals 2T-1 (group 0) and 2T (group 1): landed by barrier 2T-1 (every wave waits for
+// its own loads of tile T+1 before barrier 2T+1), slot refilled after barrier 2T+1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NST, int SWIGLU>
+__global__ __launch_bounds__(512, 1) void pp_kernel(const Prob d, const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];
+  constexpr int TBK = 32, NWAVES = 8, NTW = 4;
+  constexpr int MTW = (MT + 1) / 2;
+  constexpr int TBN = 256;
+  constexpr int AROWS = MT * 16;
+  constexpr int ROWS = AROWS + TBN;
+  constexpr int STAGE_ELEMS = ROWS * TBK;
+  constexpr int GROUPS = ROWS / 16;  // 16 rows (of 64 B) per glds wave-instruction
+  constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;
+  constexpr int REM = GROUPS % NWAVES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wave_n = wave & 3;
+  const int my_mt = grp == 0 ? MTW : MT - MTW;
+  const int my_row0 = grp == 0 ? 0 : MTW * 16;
+  const bool full = (REM == 0 || wave < REM);
+  const int my_groups = full ? GPW : GPW - 1;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = d.m_fast ? tile % d.tiles_m : tile / d.tiles_n;
+  const int tile_n = d.m_fast ? tile / d.tiles_m : tile - tile_m * d.tiles_n;
+  const int m0 = tile_m * d.panel_rows, n0 = tile_n * TBN;
+  const int m_end = min(m0 + d.panel_rows, d.M);
+  const int nkt = d.K / TBK;
+
+  unsigned long long t0c = 0, t0r = 0;
+  if (d.stamps && tid == 0) {
+    t0c = __builtin_amdgcn_s_memtime();
+    t0r = __builtin_amdgcn_s_memrealtime();
+  }
+  const int rsub = lane >> 2, cpos = lane & 3;
+  const op16_t* rptr[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + gi * NWAVES;
+    const bool is_a = g < AROWS / 16;
+    const int row = (is_a ? g : g - AROWS / 16) * 16 + rsub;
+    const int gchunk = cpos ^ swzk<TBK>(row);
+    const int idx = (is_a ? m0 : n0) + row;
+    const bool ok = g < GROUPS && (is_a ? idx < m_end : idx < d.N);
+    rptr[gi] = ok ? (is_a ? d.A : d.W) + (long)idx * d.K + gchunk * 8 : nullptr;
+  }
+  const op16_t* zsrc = zero_page + cpos * 8;
+  auto issue = [&](int kt) {
+    op16_t* sbase = lds + (kt % NST) * STAGE_ELEMS;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      if (gi < my_groups) {
+        const int g = wave + gi * NWAVES;
+        const op16_t* gp = rptr[gi] ? rptr[gi] + kt * TBK : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(sbase + g * 16 * TBK), 16, 0, 0);
+      }
+    }
+  };
+  // wait until all but the `younger` most recent tiles' loads of this wave have landed
+  auto wait_younger = [&](int younger) {
+#define WY(Y)                                                                               \
+  if (younger == Y) {                                                                       \
+    if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * GPW) : "memory");               \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * (GPW - 1)) : "memory");              \
+  }
+    WY(0) WY(1) WY(2) WY(3) WY(4)
+#undef WY
+  };
+
+  f32x4 acc[NTW][MTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int coff = (fchunk ^ swzk<TBK>(frow)) * 8;
+  const int a_off = (my_row0 + frow) * TBK + coff;
+  const int w_off = (AROWS + wave_n * 64 + frow) * TBK + coff;
+  op16x8 fa[MTW], fw[NTW];
+  auto load_frags = [&](int kt) {
+    const op16_t* base = lds + (kt % NST) * STAGE_ELEMS;
+#pragma unroll
+    for (int k = 0; k < NTW; ++k) fw[k] = *reinterpret_cast<const op16x8*>(base + w_off + k * 16 * TBK);
+#pragma unroll
+    for (int tm = 0; tm < MTW; ++tm)
+      if (tm < my_mt) fa[tm] = *reinterpret_cast<const op16x8*>(base + a_off + tm * 16 * TBK);
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int tm = 0; tm < MTW; ++tm)
+      if (tm < my_mt) {
+#pragma unroll
+        for (int tn = 0; tn < NTW; ++tn) acc[tn][tm] = mfma(fw[tn], fa[tm], acc[tn][tm]);
+      }
+  };
+
+  const int npre = min(NST, nkt);
+  for (int s2 = 0; s2 < npre; ++s2) issue(s2);
+  wait_younger(npre - 1);
+  __builtin_amdgcn_s_barrier();  // barrier -1: tile 0 visible
+  if (grp == 0) {
+    load_frags(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // interval j: group (j & 1) issues MFMAs of tile (j - grp) / 2, the other reads the fragments of its next tile
+  for (int j = 0; j < 2 * nkt; ++j) {
+    const int T = j >> 1;
+    if ((j & 1) && T + 1 < nkt) wait_younger(min(nkt - 1, T + NST - 1) - (T + 1));  // tile T+1 visible after barrier 2T+1
+    __builtin_amdgcn_s_barrier();
+    if ((j & 1) && T + NST < nkt) issue(T + NST);  // slot of tile T: both groups hold its fragments
+    if ((j & 1) == grp) {
+      __builtin_amdgcn_s_setprio(1);
+      mfmas();
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      const int TL = (j + 1 - grp) >> 1;
+      if (TL < nkt) {
+        load_frags(TL);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  }
+  if (d.stamps && tid == 0) {
+    d.stamps[blockIdx.x * 4 + 0] = t0c;
+    d.stamps[blockIdx.x * 4 + 1] = t0r;
+    d.stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+    d.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < MTW; ++tm) {
+    const int m = m0 + my_row0 + tm * 16 + (lane & 15);
+    if (tm >= my_mt || m >= m_end) continue;
+    if (SWIGLU) {
+#pragma unroll
+      for (int tn = 0; tn < NTW; tn += 2) {
+        const int n = n0 + wave_n * 64 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const f32x4 v = acc[tn][tm], g = acc[tn + 1][tm];
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(unsigned short, (_Float16)(v[r] * (g[r] / (1.f + __expf(-g[r])))));
+        const int no = (n0 + wave_n * 64 + tn * 16) / 2 + nq;
+        *reinterpret_cast<uint2*>(d.C + (long)m * (d.N / 2) + no) =
+            uint2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < NTW; ++tn) {
+        const int n = n0 + wave_n * 64 + tn * 16 + nq;
+        if (n >= d.N) continue;
+        const f32x4 v = acc[tn][tm];
+        unsigned short o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(unsigned short, (_Float16)v[r]);
+        *reinterpret_cast<uint2*>(d.C + (long)m * d.N + n) =
+            uint2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+      }
+    }
+  }
+}
+
 __global__ void fill_kernel(op16_t* p, long n, unsigned seed) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     unsigned x = (unsigned)i * 2654435761u + seed;
@@ -312,6 +488,88 @@ float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, in
   return (float)us;
 }
 
+static std::vector<unsigned short> g_ref;  // output of the last baseline run (for checking new kernels)
+static void snapshot(const Bufs& b, long n, std::vector<unsigned short>& out) {
+  out.resize((size_t)n);
+  CHK(hipMemcpy(out.data(), b.C, (size_t)n * 2, hipMemcpyDeviceToHost));
+}
+static float h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+
+template <int MT, int NST, int SWIGLU>
+float run_pp(const char* name, Bufs& b, int M, int N, int K, int panel_rows, int iters, bool check) {
+  const size_t smem = (size_t)NST * (MT * 16 + 256) * 32 * sizeof(op16_t);
+  if (smem > 160 * 1024) {
+    printf("%-44s smem %zu too large\n", name, smem);
+    return 0;
+  }
+  auto kern = pp_kernel<MT, NST, SWIGLU>;
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  Prob d;
+  d.A = b.A;
+  d.C = b.C;
+  d.M = M;
+  d.N = N;
+  d.K = K;
+  d.panel_rows = panel_rows;
+  d.tiles_m = (M + panel_rows - 1) / panel_rows;
+  d.tiles_n = (N + 255) / 256;
+  d.m_fast = 1;
+  d.pf_mode = 0;
+  d.wnext_bytes = 0;
+  d.Wnext = nullptr;
+  d.stamps = b.stamps;
+  const int grid = d.tiles_m * d.tiles_n;
+  if (check) {  // same weights as the baseline's last launch: buffer 0
+    CHK(hipMemset(b.C, 0, (size_t)M * N * 2));
+    d.W = b.W[0];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, d, b.zero);
+    CHK(hipDeviceSynchronize());
+    std::vector<unsigned short> got;
+    const long n = (long)M * (SWIGLU ? N / 2 : N);
+    snapshot(b, n, got);
+    double maxd = 0, maxr = 0;
+    for (long i = 0; i < n && i < (long)g_ref.size(); ++i) {
+      maxd = std::max(maxd, (double)fabsf(h2f(got[i]) - h2f(g_ref[i])));
+      maxr = std::max(maxr, (double)fabsf(h2f(g_ref[i])));
+    }
+    printf("%-44s check vs baseline: max |diff| %.4g (max |ref| %.4g) %s\n", name, maxd, maxr, maxd <= 2e-3 * maxr + 1e-6 ? "OK" : "MISMATCH");
+  }
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) {
+    d.W = b.W[w % b.rot];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, d, b.zero);
+  }
+  CHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) {
+    d.W = b.W[i % b.rot];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, d, b.zero);
+  }
+  CHK(hipEventRecord(e1, 0));
+  CHK(hipEventSynchronize(e1));
+  CHK(hipGetLastError());
+  float ms = 0;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = 1e3 * ms / iters;
+  std::vector<unsigned long long> st((size_t)grid * 4);
+  CHK(hipMemcpy(st.data(), b.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc, ghz;
+  for (int g = 0; g < grid; ++g) {
+    const double dc = (double)(st[g * 4 + 2] - st[g * 4 + 0]), dr = (double)(st[g * 4 + 3] - st[g * 4 + 1]);
+    if (dr > 0) {
+      cyc.push_back(dc);
+      ghz.push_back(dc / dr * 0.1);
+    }
+  }
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(ghz.begin(), ghz.end());
+  printf("%-44s pp rot %2d grid %4d smem %6zu  %7.2f us  %6.0f TF  loop %.0f cyc @ %.2f GHz\n", name, b.rot, grid, smem, us,
+         2.0 * M * N * K / (us * 1e-6) / 1e12, cyc.empty() ? 0 : cyc[cyc.size() / 2], ghz.empty() ? 0 : ghz[ghz.size() / 2]);
+  fflush(stdout);
+  return (float)us;
+}
+
 int main(int argc, char** argv) {
   const int M = 2112;
   const int iters = 48;
@@ -339,18 +597,25 @@ int main(int argc, char** argv) {
   if (want(tag)) run_cfg<WM, WN, MT, NTW, BK, NST, MODE, SW>(tag, b, M_, N_, K_, PR, iters);
 
   b.pf = 0;
+#define PP(tag, MT, NST, SW, M_, N_, K_, PR, CHECK) \
+  if (want(tag)) run_pp<MT, NST, SW>(tag, b, M_, N_, K_, PR, iters, CHECK);
+  // ---- FF-in: baseline once with weight buffer 0 last (reference output), then the ping-pong kernel
+  b.rot = 1;
+  RUN("ffin 16w 4x4 mt17 bk64 nst2 full", 4, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
+  snapshot(b, (long)M * 4096, g_ref);
+  PP("ffin pp mt17 nst4", 17, 4, 1, M, 8192, 1024, 264, true)
   b.rot = 64;
   RUN("ffin 16w 4x4 mt17 bk64 nst2 full", 4, 4, 17, 4, 64, 2, 0, 1, M, 8192, 1024, 264)
-  RUN("ffin 16w 4x4 mt17 bk64 nst2 stage-only", 4, 4, 17, 4, 64, 2, 1, 1, M, 8192, 1024, 264)
-  RUN("ffin 16w 4x4 mt17 bk64 nst2 compute-only", 4, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 2x4 mt17 bk64 nst2 compute-only", 2, 4, 17, 4, 64, 2, 2, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 4x2 mt17 ntw8 bk64 nst2 compute-only", 4, 2, 17, 8, 64, 2, 2, 1, M, 8192, 1024, 264)
-  RUN("ffin 8w 4x2 mt17 ntw8 bk64 nst2 full", 4, 2, 17, 8, 64, 2, 0, 1, M, 8192, 1024, 264)
+  PP("ffin pp mt17 nst4", 17, 4, 1, M, 8192, 1024, 264, false)
+  PP("ffin pp mt16 nst4 (256-row tiles, 9 panels)", 16, 4, 1, M, 8192, 1024, 256, false)
+  // ---- QKV
+  b.rot = 1;
   RUN("qkv 16w 4x4 mt7 bk64 nst3 full", 4, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
-  RUN("qkv 16w 4x4 mt7 bk64 nst3 compute-only", 4, 4, 7, 4, 64, 3, 2, 0, M, 3072, 1024, 104)
-  RUN("qkv 8w 2x4 mt7 bk64 nst3 full", 2, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
-  RUN("qkv 8w 2x4 mt7 bk64 nst3 compute-only", 2, 4, 7, 4, 64, 3, 2, 0, M, 3072, 1024, 104)
-  RUN("ffout 8w 2x4 mt5 ntw2 bk64 nst4 full (66x128)", 2, 4, 5, 2, 64, 4, 0, 0, M, 1024, 4096, 66)
-  RUN("ffout 8w 2x4 mt5 ntw2 bk64 nst4 compute-only", 2, 4, 5, 2, 64, 4, 2, 0, M, 1024, 4096, 66)
+  snapshot(b, (long)M * 3072, g_ref);
+  PP("qkv pp mt7 nst4", 7, 4, 0, M, 3072, 1024, 104, true)
+  b.rot = 64;
+  RUN("qkv 16w 4x4 mt7 bk64 nst3 full", 4, 4, 7, 4, 64, 3, 0, 0, M, 3072, 1024, 104)
+  PP("qkv pp mt7 nst4", 7, 4, 0, M, 3072, 1024, 104, false)
+  PP("qkv pp mt9 nst4 (132-row panels, 192 wgs)", 9, 4, 0, M, 3072, 1024, 132, false)
   return 0;
 }
