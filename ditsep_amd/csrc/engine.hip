@@ -683,6 +683,17 @@ struct dsn_ctx {
     d.act_mod = 1;
     return d;
   }
+  // development: "bm,bn,nst,bk" from the environment overrides the tile heuristic of one call site
+  void dev_tile(GemmDesc& d, const char* var) const {
+    const char* v = getenv(var);
+    int bm, bn, nstg, bk;
+    if (v && P == 1 && sscanf(v, "%d,%d,%d,%d", &bm, &bn, &nstg, &bk) == 4 && d.Cin % bk == 0) {
+      d.cfg_bm = bm;
+      d.cfg_bn = bn;
+      d.cfg_nst = nstg;
+      d.cfg_bk = bk;
+    }
+  }
   void set_act(GemmDesc& d, const ActP& a) {
     d.act = a.kind;
     d.act_a = a.a;
@@ -1414,6 +1425,7 @@ struct dsn_ctx {
             d.cfg_nst = nstg;
             d.cfg_bk = bk;
           }
+          if (d.taps * d.Cin > 512) dev_tile(d, "DSN_CONVT_DEEP_TILE");
         }
         run(d, st);
       }
@@ -1433,6 +1445,7 @@ struct dsn_ctx {
           d.out_planes = ph;
           d.out_ps = o_ps;
           set_act(d, r.act2);
+          dev_tile(d, "DSN_RU7_TILE");
           run(d, st);
         }
         {
@@ -1442,6 +1455,7 @@ struct dsn_ctx {
           d.out_ps = o_ps;
           if (j < 2) d.out_f32 = xf;
           set_act(d, next);
+          dev_tile(d, "DSN_RU1_TILE");
           run(d, st);
         }
       }
