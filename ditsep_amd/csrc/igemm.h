@@ -99,6 +99,8 @@ struct GemmDesc {
 hipError_t igemm_launch(const GemmDesc& d, int pl, hipStream_t stream);   // v1: register-staged
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream);  // v2: glds ring + split-K, auto tile
 hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, int bk, hipStream_t stream);
+// halo-resident 3x3 conv (single-plane modes, W <= 32, H*W % 256 == 0); hipErrorNotSupported when not eligible
+hipError_t igemm_halo3x3_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);

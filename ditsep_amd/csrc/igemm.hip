@@ -22,7 +22,7 @@
 #define DSN_SETPRIO 0
 #endif
 #ifndef DSN_DBG_MODE
-#define DSN_DBG_MODE 0  // development ablation builds: 1 = no in-loop staging, 2 = no MFMAs
+#define DSN_DBG_MODE 0  // development ablation builds: 1 = no in-loop staging, 2 = no MFMAs, 3 = no epilogue (halo kernel)
 #endif
 
 namespace {
@@ -38,9 +38,50 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row 
 // EPI: compile-time feature bits, so that a kernel only carries (and allocates registers for) the epilogue code it can
 // run: 1 = row statistics of the output (d.stat_out), 2 = folded-LayerNorm consumer (ln_rows), 4 = fp8 SwiGLU output.
 enum { EPI_STATS = 1, EPI_LNFOLD = 2, EPI_FP8OUT = 4 };
-template <int P, int F16, int NT, int MT, int EPI = 0>
+// LEAN: feature groups compiled OUT of the generic epilogue (the launcher promises the descriptor does not use them):
+// 1 = the DiT-only ones (RoPE, fused-QKV scaling, SwiGLU), 2 = the NCSN++-only ones (GroupNorm partials, per-item
+// bias, tanh output).  The 16-wave 256 x 256 tile kernel (128-VGPR cap) spilled ~200 registers carrying all of them.
+// 4 = the kernel seeded its accumulators with bias + per-item bias + residual before the k loop (seed_acc): the loads
+// hide under the first k-tiles instead of forming a chain of dependent round trips in front of the stores.
+enum { LEAN_NO_DIT = 1, LEAN_NO_NCSN = 2, LEAN_SEEDED = 4 };
+
+// accumulator seed of one wave: bias[n] + bbias[b][n] + resid[m][n] for its NT x MT sub-tiles (rows >= m_end: zero)
+template <int NT, int MT>
+__device__ __forceinline__ void seed_acc(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0, int lane) {
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm) {
+    const int m = mw0 + tm * 16 + (lane & 15);
+    const bool mok = m < m_end;
+    const int b = mok ? m / d.rows_per_b : 0;
+    const int j = mok ? m - b * d.rows_per_b : 0;
+    const long roff = (long)b * d.resid_bstride + (long)j * d.resid_row_elems + d.resid_off;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const int n = nw0 + tn * 16 + nq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (mok && n < d.N) {
+        if (d.bias) v = *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        if (d.bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
+        if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + roff + n);
+      }
+      acc[tn][tm] = v;
+    }
+  }
+}
+template <int P, int F16, int NT, int MT, int EPI = 0, int LEAN = 0>
 __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
                                              int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
+  const bool f_rope = !(LEAN & LEAN_NO_DIT) && d.rope_cos != nullptr;
+  const bool f_qkv = !(LEAN & LEAN_NO_DIT) && d.qkv_D > 0;
+  const bool f_swiglu = !(LEAN & LEAN_NO_DIT) && d.swiglu;
+#if DSN_DBG_MODE == 5
+  const bool f_gn = false;
+#else
+  const bool f_gn = !(LEAN & LEAN_NO_NCSN) && d.gn_stats != nullptr;
+#endif
+  const bool f_bbias = !(LEAN & LEAN_NO_NCSN) && d.bbias != nullptr;
+  const bool f_tanh = !(LEAN & LEAN_NO_NCSN) && d.f32_op == DSN_F32_TANH;
   const int nq = (lane >> 4) * 4;
   if (d.ksplit > 1) {  // raw partial sums to this slice's slab
     float* slab = d.out_f32 + (long)z * d.slab_stride;
@@ -156,8 +197,8 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
     const int j = m - b * d.rows_per_b;
     const long row_rel = (long)j * d.out_row_elems + d.out_off;
     const long row_abs = (long)b * d.out_bstride + row_rel;
-    if (!d.swiglu) {
-      if (d.rope_cos) {
+    if (!f_swiglu) {
+      if (f_rope) {
         // fused QKV epilogue: this wave's 64 columns are one 64-wide head of the q, k or v section;
         // rotary embedding on the first 32 features (pairs (c, c+16) = accumulator tiles 0 and 1 of the
         // same lane), q pre-scaled by 1/sqrt(dh)
@@ -181,24 +222,30 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
         if (rel < 0 || rel >= d.out_limit) continue;
         const long off = row_abs + n;
         f32x4 v = acc[tn][tm];
-        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
-        if (d.qkv_D > 0 && n < d.qkv_D) v *= d.q_scale;  // fused q|k|v projection: q (bias included) pre-scaled
-        if (d.bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
-        if (d.resid)
-          v += *reinterpret_cast<const f32x4*>(d.resid + (long)b * d.resid_bstride + (long)j * d.resid_row_elems +
-                                               d.resid_off + n);
+        if constexpr ((LEAN & LEAN_SEEDED) == 0) {
+          if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+          if (f_qkv && n < d.qkv_D) v *= d.q_scale;  // fused q|k|v projection: q (bias included) pre-scaled
+          if (f_bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
+          if (d.resid)
+            v += *reinterpret_cast<const f32x4*>(d.resid + (long)b * d.resid_bstride + (long)j * d.resid_row_elems +
+                                                 d.resid_off + n);
+        }
         v *= d.out_scale;
-        if (d.gn_stats) {
+        if (f_gn) {
           gs[tn] += (v[0] + v[1]) + (v[2] + v[3]);
           acc[tn][tm] = v;  // kept for the second (deviation) pass below
         }
         if (d.out_f32) {
           f32x4 o = v;
-          if (d.f32_op == DSN_F32_TANH) {
+          if (f_tanh) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = tanhf(v[r]);
           }
+#if DSN_DBG_MODE == 4
+          asm volatile("" ::"v"(o));
+#else
           *reinterpret_cast<f32x4*>(d.out_f32 + off) = o;
+#endif
         }
         if (d.out_planes) {
           f32x4 a = v;
@@ -284,7 +331,7 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
       }
     }
   }
-  if (d.gn_stats && mw0 < m_end) {
+  if (f_gn && mw0 < m_end) {
     // the wave's rows are one whole 64-row slice of one item (rows_per_b % 64 == 0): per (column sub-tile, 4-channel
     // lane group) mean over the 16 row lanes x MT sub-tiles x 4 channels, then the squared deviations, one plain
     // store per quad -- no atomics, every launch writes the same bits
@@ -314,10 +361,10 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT]
   }
 }
 
-template <int P, int F16>
+template <int P, int F16, int LEAN = 0>
 __device__ __forceinline__ void epilogue_tile(const GemmDesc& d, f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
                                               int z) {
-  epilogue_gen<P, F16, 4, 4>(d, acc, mw0, d.M, nw0, lane, z);
+  epilogue_gen<P, F16, 4, 4, 0, LEAN>(d, acc, mw0, d.M, nw0, lane, z);
 }
 
 template <int P, int F16>
@@ -545,7 +592,7 @@ __device__ __forceinline__ int swzk(int row) {
   return TBK == 32 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
 }
 
-template <int P, int F16, int TBM, int TBN, int NST, int TBK>
+template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0>
 __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,
                                                                                  const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows][TBK]
@@ -624,10 +671,14 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   };
 
   f32x4 acc[4][4];
+  if constexpr ((LEAN & LEAN_SEEDED) != 0) {
+    seed_acc<4, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane);  // issued before any glds: lands first (in order)
+  } else {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // fragment rows are (tile*16 + frow) with tile offsets multiples of 16: the swizzle only sees frow
   const int frow = lane & 15, fchunk = lane >> 4;
@@ -694,7 +745,189 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #endif
     }
   }
-  epilogue_tile<P, F16>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+  epilogue_tile<P, F16, LEAN>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+}
+
+// ============================================================================
+// Halo-resident 3x3 convolution (NCSN++ `ddpm_conv3x3` on channels-last images [B][H*W][C], single-plane modes).
+// igemm2_kernel stages the activation tile once per tap (9 x per channel chunk).  Here a workgroup owns TBM
+// consecutive rows of ONE image (TBM | H*W) x 128 output channels and, per 32-channel chunk, stages the rows
+// [first - (W+1), last + (W+1)] ONCE (double buffered) -- every tap (dy, dx) is the same LDS chunk read at a row shift
+// of dy*W + dx -- while the weights stream through their own 4-slot ring, one (tap, chunk) tile per k-step.
+// Staged bytes per workgroup at 256 x 128: 0.38 MB instead of 0.89 MB (Cin = 128).
+//   * rows beyond the image (y = -1, y = H) are zero-page rows of the halo;
+//   * the x borders are the only taps that read a VALID neighbour which must count as zero (x = 0 with dx = -1
+//     reads the previous image row's last pixel): those A fragments are zeroed in registers, per lane;
+//   * the 64-byte-row swizzle of igemm2 (chunk ^ (-(row >> 2) & 3)) is conflict-free for any row shift: 16 consecutive
+//     rows never hold two rows 16 apart, and rows of the partial first / last 4-row group differ in row % 4.
+// Ring protocol as everywhere (counted vmcnt + lgkmcnt(0) + raw barrier); the halo of chunk c+1 is issued at tap 0
+// of chunk c, right before that iteration's weight tile, so for the next NSTW-2 iterations it is YOUNGER than the
+// weight tile being waited for and the allowed outstanding count is raised by its (wave-uniform) instruction count.
+// ============================================================================
+template <int F16, int TBM>
+__global__ __launch_bounds__((TBM / 64) * 2 * 64, 4) void igemm_halo3x3_kernel(const GemmDesc d,
+                                                                                const op16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [2][HRMAX][32] halo | [NSTW][128][32] weights | dummy
+  constexpr int TBN = 128, CK = 32, NSTW = 4;
+  constexpr int WM_ = TBM / 64, WN_ = 2, NWAVES = WM_ * WN_;
+  constexpr int HRMAX = ((TBM + 2 * 33 + 15) / 16) * 16;        // W <= 32
+  constexpr int HGW = (HRMAX / 16 + NWAVES - 1) / NWAVES;       // halo glds instructions per wave per chunk (uniform)
+  constexpr int GW = (TBN / 16) / NWAVES >= 1 ? (TBN / 16) / NWAVES : 1;  // weight glds per wave per k-tile
+  static_assert((TBN / 16) % NWAVES == 0 || NWAVES > TBN / 16, "weight row groups over the waves");
+  constexpr int HBUF = HRMAX * CK, WBUF = TBN * CK;
+  op16_t* const hbuf = lds;
+  op16_t* const wring = lds + 2 * HBUF;
+  op16_t* const dummy = wring + NSTW * WBUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_, wn = wave - wm * WN_;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tile_m = t / d.tiles_n, tile_n = t - tile_m * d.tiles_n;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  const int HW = d.rows_per_b, W = d.img_w;
+  const int b = m0 / HW, j0 = m0 - b * HW;  // the tile lies inside image b
+  const int HR = ((TBM + 2 * (W + 1) + 15) / 16) * 16, HG = HR / 16;
+
+  const int Ktot = 9 * d.Cin;
+  const int nchunks = d.Cin / CK;
+  const int nkt = 9 * nchunks;
+
+  // ---- loader state ----
+  const int rsub = lane >> 2, cpos = lane & 3;
+  const op16_t* hsrc[HGW];
+  int hstep[HGW];
+  op16_t* hdst[HGW];
+#pragma unroll
+  for (int gi = 0; gi < HGW; ++gi) {
+    const int g = wave + gi * NWAVES;
+    const int h = g * 16 + rsub;
+    const int j = j0 - (W + 1) + h;
+    const bool ok = g < HG && j >= 0 && j < HW;
+    const int gchunk = cpos ^ swzk<32>(h);
+    hsrc[gi] = ok ? d.A + (long)b * d.in_bstride + (long)j * d.in_row_elems + gchunk * 8 : zero_page + cpos * 8;
+    hstep[gi] = ok ? CK : 0;
+    hdst[gi] = g < HG ? hbuf + g * 16 * CK : dummy;
+  }
+  const op16_t* wsrc[GW];
+  int wstep[GW];
+#pragma unroll
+  for (int gi = 0; gi < GW; ++gi) {
+    const int g = wave * GW + gi;
+    const int row = g * 16 + rsub;
+    const bool live = g < TBN / 16;
+    const bool ok = live && n0 + row < d.N;
+    const int gchunk = cpos ^ swzk<32>(row);
+    wsrc[gi] = ok ? d.W + (long)(n0 + row) * Ktot + gchunk * 8 : zero_page + cpos * 8;
+    wstep[gi] = ok ? 1 : 0;
+  }
+  auto issue_halo = [&](int c) {
+    op16_t* base = (c & 1) ? hbuf + HBUF : hbuf;
+#pragma unroll
+    for (int gi = 0; gi < HGW; ++gi) {
+      const op16_t* g = hsrc[gi] + (long)c * hstep[gi];
+      op16_t* dst = hdst[gi] == dummy ? dummy : hdst[gi] + (base - hbuf);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  int wi_c = 0, wi_tap = 0;  // (chunk, tap) of the next weight tile to issue
+  auto issue_w = [&](int slot) {
+    const long off = (long)wi_tap * d.Cin + wi_c * CK;
+#pragma unroll
+    for (int gi = 0; gi < GW; ++gi) {
+      const int g = wave * GW + gi;
+      const op16_t* gp = wsrc[gi] + off * wstep[gi];
+      op16_t* dst = g < TBN / 16 ? wring + slot * WBUF + g * 16 * CK : dummy;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    if (++wi_tap == 9) {
+      wi_tap = 0;
+      ++wi_c;
+    }
+  };
+
+  f32x4 acc[4][4];
+  seed_acc<4, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane);  // before any glds: these loads land first (in order)
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int w_off = (wn * 64 + frow) * CK + ((fchunk ^ swzk<32>(frow)) * 8);
+  // x-border flags of this lane's 4 output rows (row sub-tiles tm): bit tm of xl / xr
+  unsigned xl = 0, xr = 0;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int x = (j0 + wm * 64 + tm * 16 + frow) % W;
+    if (x == 0) xl |= 1u << tm;
+    if (x == W - 1) xr |= 1u << tm;
+  }
+
+  issue_halo(0);
+#pragma unroll
+  for (int s2 = 0; s2 < NSTW - 1; ++s2)
+    if (s2 < nkt) issue_w(s2);
+
+  int c = 0, tap = 0;
+  for (int i = 0; i < nkt; ++i) {
+    const int younger = min(NSTW - 2, nkt - 1 - i);
+    const bool halo_younger = (tap == 1 || tap == 2) && c + 1 < nchunks;  // halo(c+1) issued at tap 0, NSTW = 4
+    if (halo_younger)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GW + HGW) : "memory");
+    else if (younger >= 2)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * GW) : "memory");
+    else if (younger == 1)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GW) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if DSN_DBG_MODE != 1
+    if (tap == 0 && c + 1 < nchunks) issue_halo(c + 1);
+    if (i + NSTW - 1 < nkt) issue_w((i + NSTW - 1) % NSTW);
+#endif
+
+    const op16_t* hb = (c & 1) ? hbuf + HBUF : hbuf;
+    const op16_t* wb = wring + (i % NSTW) * WBUF;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int h0 = wm * 64 + frow + (W + 1) + dy * W + dx;  // halo row of sub-tile 0; +16 per sub-tile keeps the swizzle
+    const int a_off = h0 * CK + ((fchunk ^ swzk<32>(h0)) * 8);
+    op16x8 fa[4], fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      fa[k] = *reinterpret_cast<const op16x8*>(hb + a_off + k * 16 * CK);
+      fw[k] = *reinterpret_cast<const op16x8*>(wb + w_off + k * 16 * CK);
+    }
+    if (dx != 0) {
+      const unsigned mk = dx < 0 ? xl : xr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((mk >> k) & 1u) fa[k] = op16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#if DSN_DBG_MODE == 2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(fa[k]), "v"(fw[k]));
+#else
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
+#endif
+    if (++tap == 9) {
+      tap = 0;
+      ++c;
+    }
+  }
+#if DSN_DBG_MODE == 3
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) asm volatile("" ::"v"(acc[a][bb]));
+#else
+  epilogue_gen<1, F16, 4, 4, 0, LEAN_NO_DIT | LEAN_SEEDED>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane, 0);
+#endif
 }
 
 // ============================================================================
@@ -892,7 +1125,7 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
     }
   }
   // rows m0 + my_row0 + tm*16 ...; wave rows 1..3 never touch their (unused) 5th sub-tile: mask it by row
-  epilogue_gen<P, F16, 4, MTW, EPI>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane,
+  epilogue_gen<P, F16, 4, MTW, EPI, LEAN_NO_NCSN>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane,
                                     z, ((EPI & EPI_LNFOLD) && d.ln_stats) ? ln_rows : nullptr, m0);
 }
 
@@ -1153,19 +1386,19 @@ const op16_t* zero_page() {
   return z;
 }
 
-template <int P, int F16, int TBM, int TBN, int NST, int TBK>
+template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0>
 hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = cdiv(d.M, TBM);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (TBM + TBN) * TBK * sizeof(op16_t);
-  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST, TBK>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem, stream,
-                     d, zp);
+  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem,
+                     stream, d, zp);
   return hipGetLastError();
 }
 
@@ -1181,6 +1414,15 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
+  // conv-stack descriptors (Oobleck: bias / activation / residual / fp32 + plane outputs only) take the lean epilogue
+  const bool lean = !d.rope_cos && d.qkv_D <= 0 && !d.swiglu && !d.gn_stats && !d.bbias && d.f32_op != DSN_F32_TANH &&
+                    d.ksplit <= 1;
+#define CFGL(P_, BM_, BN_, NS_, BK_)                                                                   \
+  if (lean && planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)                       \
+    return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_, LEAN_NO_DIT | LEAN_NO_NCSN | LEAN_SEEDED>(d, zp, stream)      \
+               : launch_cfg<P_, 0, BM_, BN_, NS_, BK_, LEAN_NO_DIT | LEAN_NO_NCSN | LEAN_SEEDED>(d, zp, stream);
+  CFGL(1, 256, 256, 2, 64) CFGL(1, 256, 256, 3, 32) CFGL(2, 256, 256, 2, 32) CFGL(1, 256, 128, 3, 64)
+#undef CFGL
 #define CFG(P_, BM_, BN_, NS_, BK_)                                                   \
   if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)              \
     return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_>(d, zp, stream)                 \
@@ -1196,12 +1438,44 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
   return hipErrorInvalidValue;
 }
 
+// halo-resident 3x3 conv: eligibility + launch (hipErrorNotSupported = not eligible, caller falls back)
+template <int F16, int TBM>
+static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
+  d.tiles_m = d.M / TBM;
+  d.tiles_n = cdiv(d.N, 128);
+  constexpr int HRMAX = ((TBM + 2 * 33 + 15) / 16) * 16;
+  const size_t smem = (size_t)(2 * HRMAX * 32 + 4 * 128 * 32 + 16 * 32) * sizeof(op16_t);
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL((igemm_halo3x3_kernel<F16, TBM>), dim3(d.tiles_m * d.tiles_n), dim3((TBM / 64) * 2 * 64), smem,
+                     stream, d, zp);
+  return hipGetLastError();
+}
+hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream) {
+  const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
+  const GemmDesc& d = din;
+  if (planes != 1 || d.img_w <= 0 || d.img_w > 32 || d.taps != 9 || d.Cin % 32 != 0 || d.in_stride != 1 ||
+      d.ksplit > 1 || d.swiglu || d.rows_per_b % 256 != 0 || d.rows_per_b != d.img_w * d.img_h || d.M % 256 != 0 ||
+      d.in_pad != 0)
+    return hipErrorNotSupported;
+  const op16_t* zp = zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+  return f16 ? launch_halo_t<1, 256>(d, zp, stream) : launch_halo_t<0, 256>(d, zp, stream);
+}
+
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
   const int planes = PL_COUNT(pl);
   // Tile choice from the measured sweeps (scripts/gemm_bench.py; profiles/r01_gemm_sweep_*.log).
   // The kernel is L2->LDS bound and, at the DiT's M ~ 2k rows, wave-quantisation bound: take the
   // biggest tile whose grid still fills 256 CUs.
   if (d.cfg_bm > 0) return igemm2_launch_cfg(d, pl, d.cfg_bm, d.cfg_bn, d.cfg_nst, d.cfg_bk, stream);
+  if (d.img_w > 0 && getenv("DSN_NO_HALO") == nullptr) {  // 3x3 convs: halo-resident kernel where it applies
+    const hipError_t e = igemm_halo3x3_launch(d, pl, stream);
+    if (e != hipErrorNotSupported) return e;
+  }
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
   auto tiles = [&](int tm, int tn) { return (long)cdiv(d.M, tm) * cdiv(d.N, tn) * std::max(d.ksplit, 1); };

@@ -56,30 +56,44 @@ __global__ void ncsn_pack_kernel(const float* __restrict__ xt, const float* __re
 
 // GroupNorm statistics as slice partials: stats[B][S][C/4][2] = (mean, M2) of the (<= 64 rows) x 4 channels of slice
 // s = rows [64 s, 64 s + 64) of the item, quad q -- the layout the GEMM epilogue writes for tensors it produces
-// (GemmDesc::gn_stats).  One thread per (slice, quad): two passes over its <= 256 values, plain stores.
-__global__ void gn_stats_kernel(const float* __restrict__ x, long bstride, int rstride, int C, int HW,
-                                float* __restrict__ stats) {
+// (GemmDesc::gn_stats).  One wave per (slice, 16 quads): lane (quad ql, row part rp) keeps its 16 rows x 4 channels in
+// registers (one pass over memory), the four row parts meet through a fixed xor tree; plain stores.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long bstride, int rstride, int C,
+                                                       int HW, float* __restrict__ stats) {
   const int nq = C >> 2;
+  const int nqb = (nq + 15) >> 4;
   const int S = (HW + 63) >> 6;
   const int b = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S * nq; i += gridDim.x * blockDim.x) {
-    const int sl = i / nq, q = i - sl * nq;
-    const int r0 = sl * 64, r1 = min(r0 + 64, HW);
-    const float* xp = x + (long)b * bstride + q * 4;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)r * rstride);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = s / (float)((r1 - r0) * 4);
-    float m2 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)r * rstride);
+  const int lane = threadIdx.x & 63, ql = lane & 15, rp = lane >> 4;
+  const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= S * nqb) return;  // whole waves leave together
+  const int sl = item / nqb, q = (item - sl * nqb) * 16 + ql;
+  const int r0 = sl * 64 + rp * 16, r1 = min(sl * 64 + 64, HW);
+  const bool live = q < nq;
+  const float* xp = x + (long)b * bstride + (live ? q : 0) * 4;
+  f32x4 v[16];
+  float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m2 += (v[k] - mean) * (v[k] - mean);
-    }
-    *reinterpret_cast<float2*>(stats + (((long)b * S + sl) * nq + q) * 2) = float2{mean, m2};
+  for (int k = 0; k < 16; ++k) {
+    const bool ok = live && r0 + k < r1;
+    v[k] = ok ? *reinterpret_cast<const f32x4*>(xp + (long)(r0 + k) * rstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float cnt = (float)((r1 - sl * 64) * 4);
+  const float mean = sum / cnt;
+  float m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (r0 + k < r1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m2 += (v[k][c] - mean) * (v[k][c] - mean);
+    }
+  }
+  m2 += __shfl_xor(m2, 16, 64);
+  m2 += __shfl_xor(m2, 32, 64);
+  if (live && rp == 0) *reinterpret_cast<float2*>(stats + (((long)b * S + sl) * nq + q) * 2) = float2{mean, m2};
 }
 
 // y = (x - mean) * rstd * gamma + beta [, SiLU]  ->  contiguous [B][HW][C] fp32 and/or planes.
@@ -94,27 +108,39 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, long bstride, int r
   const int cpg = C / G, qpg = cpg >> 2;
   const int S = (HW + 63) >> 6;
   const int b = blockIdx.y;
-  if ((int)threadIdx.x < G) {
-    const int g = threadIdx.x;
-    const float2* sp = reinterpret_cast<const float2*>(stats) + (long)b * S * nq + g * qpg;
+  {
+    // statistics prologue: TPG lanes per group share the (slice, quad) partials; lane-local sums in index order, then a
+    // fixed xor tree -- the same bits on every launch.  Two passes (mean, then M2 about it: Chan's combine).
+    int tpg = 1;
+    while (tpg < 64 && G * tpg * 2 <= (int)blockDim.x) tpg *= 2;
+    const int g = threadIdx.x / tpg, sub = threadIdx.x - g * tpg;
+    const bool live = g < G;
+    const float2* sp = reinterpret_cast<const float2*>(stats) + (long)b * S * nq + (live ? g : 0) * qpg;
+    const int items = S * qpg;
     float wsum = 0.f;
-    for (int sl = 0; sl < S; ++sl) {
-      const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
-      for (int q = 0; q < qpg; ++q) wsum += cnt * sp[(long)sl * nq + q].x;
-    }
+    if (live)
+      for (int it = sub; it < items; it += tpg) {
+        const int sl = it / qpg, q = it - sl * qpg;
+        const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
+        wsum += cnt * sp[(long)sl * nq + q].x;
+      }
+    for (int o = tpg >> 1; o >= 1; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
     const float ntot = (float)HW * (float)cpg;
     const float mean = wsum / ntot;
     float m2 = 0.f;
-    for (int sl = 0; sl < S; ++sl) {
-      const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
-      for (int q = 0; q < qpg; ++q) {
+    if (live)
+      for (int it = sub; it < items; it += tpg) {
+        const int sl = it / qpg, q = it - sl * qpg;
+        const float cnt = (float)((min(sl * 64 + 64, HW) - sl * 64) * 4);
         const float2 pr = sp[(long)sl * nq + q];
         const float dm = pr.x - mean;
         m2 += pr.y + cnt * dm * dm;
       }
+    for (int o = tpg >> 1; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+    if (live && sub == 0) {
+      gm[g] = mean;
+      gr[g] = rsqrtf(m2 / ntot + eps);
     }
-    gm[g] = mean;
-    gr[g] = rsqrtf(m2 / ntot + eps);
   }
   __syncthreads();
   const int r_begin = blockIdx.x * rows_per_block, r_end = min(r_begin + rows_per_block, HW);
@@ -242,8 +268,8 @@ void launch_gn_stats(const float* x, long bstride, int rstride, int C, int G, in
                      hipStream_t st) {
   if (G > 64 || C % (4 * G) != 0) return;  // unsupported shape: caller validates (engine: C <= 1024)
   const int S = (HW + 63) / 64;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv((long)S * (C / 4), 64), B), dim3(64), 0, st, x, bstride, rstride, C, HW,
-                     stats);
+  const long items = (long)S * cdiv(C / 4, 16);  // one wave each
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(items, 4), B), dim3(256), 0, st, x, bstride, rstride, C, HW, stats);
 }
 void launch_gn_apply(const float* x, long bstride, int rstride, int C, int G, int B, int HW, const float* stats,
                      const float* gamma, const float* beta, float eps, int silu, float* of, op16_t* op, long ps,
