@@ -764,8 +764,8 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 // of chunk c, right before that iteration's weight tile, so for the next NSTW-2 iterations it is YOUNGER than the
 // weight tile being waited for and the allowed outstanding count is raised by its (wave-uniform) instruction count.
 // ============================================================================
-template <int F16, int TBM>
-__global__ __launch_bounds__((TBM / 64) * 2 * 64, 4) void igemm_halo3x3_kernel(const GemmDesc d,
+template <int F16, int TBM, int MINW>
+__global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kernel(const GemmDesc d,
                                                                                 const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [2][HRMAX][32] halo | [NSTW][128][32] weights | dummy
   constexpr int TBN = 128, CK = 32, NSTW = 4;
@@ -1439,7 +1439,11 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
 }
 
 // halo-resident 3x3 conv: eligibility + launch (hipErrorNotSupported = not eligible, caller falls back)
-template <int F16, int TBM>
+// MINW = 4: registers capped at 128 so that two 8-wave workgroups share a CU (grids of >= 2 workgroups per CU: the
+// epilogue spills ~60 registers but the pair hides each other's barriers); MINW = 1: uncapped (162 VGPRs, one workgroup
+// per CU) for grids that cannot put two on a CU anyway.  Measured (C2 batch): level 0 (512 workgroups) 91 vs 101 us,
+// level 1 (256 workgroups) 88 vs 80 us.
+template <int F16, int TBM, int MINW>
 static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = d.M / TBM;
   d.tiles_n = cdiv(d.N, 128);
@@ -1447,23 +1451,28 @@ static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream
   const size_t smem = (size_t)(2 * HRMAX * 32 + 4 * 128 * 32 + 16 * 32) * sizeof(op16_t);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM, MINW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((igemm_halo3x3_kernel<F16, TBM>), dim3(d.tiles_m * d.tiles_n), dim3((TBM / 64) * 2 * 64), smem,
+  hipLaunchKernelGGL((igemm_halo3x3_kernel<F16, TBM, MINW>), dim3(d.tiles_m * d.tiles_n), dim3((TBM / 64) * 2 * 64), smem,
                      stream, d, zp);
   return hipGetLastError();
 }
 hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream) {
   const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   const GemmDesc& d = din;
+  // 128-row images (NCSN++ level 2, 128 workgroups of 4 waves) measured slower than igemm2's 128 x 128 x BK 64 tiles
+  // (62 vs 55 us): not routed here
   if (planes != 1 || d.img_w <= 0 || d.img_w > 32 || d.taps != 9 || d.Cin % 32 != 0 || d.in_stride != 1 ||
       d.ksplit > 1 || d.swiglu || d.rows_per_b % 256 != 0 || d.rows_per_b != d.img_w * d.img_h || d.M % 256 != 0 ||
       d.in_pad != 0)
     return hipErrorNotSupported;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-  return f16 ? launch_halo_t<1, 256>(d, zp, stream) : launch_halo_t<0, 256>(d, zp, stream);
+  const long wgs = (long)(d.M / 256) * cdiv(d.N, 128);
+  if (wgs >= 2 * 256)  // MI355X: 256 CUs
+    return f16 ? launch_halo_t<1, 256, 4>(d, zp, stream) : launch_halo_t<0, 256, 4>(d, zp, stream);
+  return f16 ? launch_halo_t<1, 256, 1>(d, zp, stream) : launch_halo_t<0, 256, 1>(d, zp, stream);
 }
 
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
@@ -1576,20 +1585,24 @@ hipError_t igemm_skinny_launch(const GemmDesc& din, int pl, hipStream_t stream) 
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
   if (PL_COUNT(pl) != 1 || d.taps != 1 || d.in_stride != 1 || d.in_pad != 0 || d.rows_per_b != d.M || d.img_w > 0 ||
-      d.M <= 0 || d.M > 48 || d.N <= 0 || d.Cin % 32 != 0 || d.N % 4 != 0 || d.gn_stats || d.stat_out || d.ln_stats ||
+      d.M <= 0 || d.M > 64 || d.N <= 0 || d.Cin % 32 != 0 || d.N % 4 != 0 || d.gn_stats || d.stat_out || d.ln_stats ||
       d.out_fp8)
     return hipErrorInvalidValue;
   if (d.swiglu && d.N % 32 != 0) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu || d.ksplit > d.Cin / 32)) return hipErrorInvalidValue;
   const int grid = ((d.N + 31) / 32) * d.ksplit;
-  const int mt = (d.M + 15) / 16;
+  // every M <= 48 runs the 3-sub-tile instantiation (rows beyond M are clamped re-reads, masked in the epilogue): the
+  // 1- and 2-sub-tile instantiations of the same source measured 2.5x SLOWER (M = 17: FF-in 35.7 vs 12.4 us), which
+  // is what had made the skinny path look like a loss below 33 rows
+  int mt = std::max((d.M + 15) / 16, 3);
+  if (const char* f = getenv("DSN_SKINNY_MT")) mt = std::max(mt, atoi(f));  // development
 #define SK(MT_)                                                                                     \
   if (mt == MT_) {                                                                                  \
     if (PL_F16(pl)) hipLaunchKernelGGL((igemm_skinny_kernel<1, MT_>), dim3(grid), dim3(256), 0, stream, d); \
     else hipLaunchKernelGGL((igemm_skinny_kernel<0, MT_>), dim3(grid), dim3(256), 0, stream, d);     \
     return hipGetLastError();                                                                       \
   }
-  SK(1) SK(2) SK(3)
+  SK(3) SK(4)
 #undef SK
   return hipErrorInvalidValue;
 }
