@@ -1416,17 +1416,10 @@ struct dsn_ctx {
         d.out_ps = o_ps;
         set_act(d, b.ru[0].act0);
         {
-          // Shallow-K phase GEMMs (the last up-sampling layers: K = 2 x 128 or 2 x 256, output 6 B per element) are
-          // store-bound: a 3-stage 256 x 128 tile beats the 256 x 256 default there
-          static const char* ct = getenv("DSN_CONVT_TILE");  // "bm,bn,nst,bk" (development)
-          int bm = 256, bn = 128, nstg = 3, bk = 64;  // measured: 256x128x3 8.3 ms, 256x256x2 9.2 ms, 128x128x3 13.4 ms (5 launches)
-          if (ct) sscanf(ct, "%d,%d,%d,%d", &bm, &bn, &nstg, &bk);
-          if (P == 1 && d.taps * d.Cin <= 512 && d.Cin % bk == 0 && bm > 0) {
-            d.cfg_bm = bm;
-            d.cfg_bn = bn;
-            d.cfg_nst = nstg;
-            d.cfg_bk = bk;
-          }
+          // Shallow-K phase GEMMs (the last up-sampling layers: K = 2 x 128 or 2 x 256): while the 256 x 256 kernel
+          // spilled ~200 registers a 3-stage 256 x 128 tile was faster there (8.3 vs 9.2 ms over the 5 layers); with
+          // the lean epilogue the default 256 x 256 x BK 64 tile wins again (6.2 vs 7.3 ms) -- override kept for sweeps
+          if (d.taps * d.Cin <= 512) dev_tile(d, "DSN_CONVT_TILE");
           if (d.taps * d.Cin > 512) dev_tile(d, "DSN_CONVT_DEEP_TILE");
         }
         run(d, st);

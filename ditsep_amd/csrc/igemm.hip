@@ -1422,6 +1422,7 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
     return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_, LEAN_NO_DIT | LEAN_NO_NCSN | LEAN_SEEDED>(d, zp, stream)      \
                : launch_cfg<P_, 0, BM_, BN_, NS_, BK_, LEAN_NO_DIT | LEAN_NO_NCSN | LEAN_SEEDED>(d, zp, stream);
   CFGL(1, 256, 256, 2, 64) CFGL(1, 256, 256, 3, 32) CFGL(2, 256, 256, 2, 32) CFGL(1, 256, 128, 3, 64)
+  CFGL(1, 256, 128, 3, 32) CFGL(1, 256, 128, 2, 64) CFGL(1, 128, 128, 3, 32) CFGL(1, 128, 128, 2, 64)
 #undef CFGL
 #define CFG(P_, BM_, BN_, NS_, BK_)                                                   \
   if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)              \

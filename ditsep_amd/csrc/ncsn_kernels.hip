@@ -144,24 +144,37 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, long bstride, int r
   }
   __syncthreads();
   const int r_begin = blockIdx.x * rows_per_block, r_end = min(r_begin + rows_per_block, HW);
-  const long total4 = (long)(r_end - r_begin) * nq;
-  for (long i = threadIdx.x; i < total4; i += blockDim.x) {
-    const int q = (int)(i % nq);
-    const int r = r_begin + (int)(i / nq);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bstride + (long)r * rstride + q * 4);
-    const int g = (q * 4) / cpg;
-    const float mean = gm[g], rstd = gr[g];
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + q * 4);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + q * 4);
-    f32x4 o;
+  const int total4 = (r_end - r_begin) * nq;
+  const float* xb = x + (long)b * bstride;
+  constexpr int UN = 4;  // independent loads in flight per thread (one per iteration left the kernel latency-bound)
+  for (int i0 = threadIdx.x; i0 < total4; i0 += UN * blockDim.x) {
+    f32x4 v[UN];
+    int q[UN], r[UN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float t = (v[k] - mean) * rstd * ga[k] + be[k];
-      o[k] = silu ? dsn_silu(t) : t;
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * blockDim.x;
+      const bool ok = i < total4;
+      q[u] = ok ? i % nq : 0;
+      r[u] = ok ? r_begin + i / nq : r_begin;
+      v[u] = *reinterpret_cast<const f32x4*>(xb + (long)r[u] * rstride + q[u] * 4);
     }
-    const long oi = ((long)b * HW + r) * nq + q;
-    if (of) reinterpret_cast<f32x4*>(of)[oi] = o;
-    if (op) store_planes4(op, ps, planes, oi * 4, o);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (i0 + u * (int)blockDim.x >= total4) break;
+      const int g = (q[u] * 4) / cpg;
+      const float mean = gm[g], rstd = gr[g];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + q[u] * 4);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + q[u] * 4);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = (v[u][k] - mean) * rstd * ga[k] + be[k];
+        o[k] = silu ? dsn_silu(t) : t;
+      }
+      const long oi = ((long)b * HW + r[u]) * nq + q[u];
+      if (of) reinterpret_cast<f32x4*>(of)[oi] = o;
+      if (op) store_planes4(op, ps, planes, oi * 4, o);
+    }
   }
 }
 

@@ -2,7 +2,7 @@
 PART=score and PART=decode) into HBM bytes per launch of each kernel, per DiT score call and per decode, and write
 profiles/<tag>.json.  gfx950 corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 64 B per 128-B
 request of wide coalesced reads -> doubled; WRITE_SIZE exact; both in KiB.
-usage: pmc_summary.py <score_fetch_dir> <score_write_dir> <decode_fetch_dir> <decode_write_dir> <out.json> [commit]"""
+usage: pmc_summary.py <score_fetch_dir> <score_write_dir> <decode_fetch_dir|-> <decode_write_dir|-> <out.json> [commit] [note]"""
 import collections, csv, glob, json, re, sys
 
 SETUP = ("pack_weight", "wn_scale", "snake_params", "packed_row_sum", "bias_plus_wbeta", "pack_bias", "randn", "fill", "copyBuffer",
@@ -42,7 +42,7 @@ def part(fetch_dir, write_dir, calls):
 
 
 score, score_total = part(sys.argv[1], sys.argv[2], 2)
-decode, decode_total = part(sys.argv[3], sys.argv[4], 1)
+decode, decode_total = part(sys.argv[3], sys.argv[4], 1) if sys.argv[3] != "-" else ({}, None)
 sites = {}
 for site, pat in SITES.items():
     for table in (score, decode):
@@ -50,7 +50,8 @@ for site, pat in SITES.items():
             if pat in name:
                 sites[site] = {"kernel": name, **r}
 out = {"commit": sys.argv[6] if len(sys.argv) > 6 else None,
-       "note": "batch 64, T=32, fp16 headline mode; hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md",
+       "note": (sys.argv[7] + "; " if len(sys.argv) > 7 else "") +
+               "batch 64, T=32, fp16 headline mode; hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md",
        "score_call_hbm_bytes": score_total, "decode_hbm_bytes": decode_total, "sites": sites,
        "score_kernels": score, "decode_kernels": decode}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
