@@ -45,8 +45,12 @@ struct GemmDesc {
   float* gn_stats;
   int gn_G, gn_cpg;
   float* out_f32;      // or null
-  int f32_op;          // DSN_F32_*
+  // (out_scale sits in the 8-byte-aligned half of its slot on purpose: with f32_op first, kernels that compile f32_op out
+  // fetched the kernarg chunk [out_scale | out_planes | ...] as one 16-byte load starting at an odd dword, could not
+  // hold the pointer in an aligned SGPR pair, parked the chunk in SCRATCH and re-read it -- with s_waitcnt vmcnt(0), i.e.
+  // behind every store already issued -- once per 16x16 output tile of the epilogue)
   float out_scale;     // applied after bias + residual
+  int f32_op;          // DSN_F32_*
   op16_t* out_planes;  // or null: act(out) written as P planes
   long out_ps;
   int act;             // DSN_ACT_*

@@ -70,8 +70,13 @@ __device__ __forceinline__ void seed_acc(const GemmDesc& d, f32x4 (&acc)[NT][MT]
   }
 }
 template <int P, int F16, int NT, int MT, int EPI = 0, int LEAN = 0>
-__device__ __forceinline__ void epilogue_gen(const GemmDesc& d, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
+__device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
                                              int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
+  // A private copy (scalarised by the compiler): read through the kernel-argument reference, descriptor fields were
+  // re-fetched after every output store -- the vector stores may alias anything as far as the compiler knows -- from a
+  // scratch copy of the argument chunk, behind s_waitcnt vmcnt(0): every 16x16 tile's stores waited for the previous
+  // tile's to complete.
+  const GemmDesc d = d_arg;
   const bool f_rope = !(LEAN & LEAN_NO_DIT) && d.rope_cos != nullptr;
   const bool f_qkv = !(LEAN & LEAN_NO_DIT) && d.qkv_D > 0;
   const bool f_swiglu = !(LEAN & LEAN_NO_DIT) && d.swiglu;

@@ -370,7 +370,12 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
         hi[r] = h;
       }
       *reinterpret_cast<op16x4*>(lds + m * C + (((n >> 3) + 2 * m) & 15) * 8 + (n & 7)) = hi;
-      acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the 1x1 conv accumulates ON TOP of bias + residual: these loads travel while the activation above and the four
+      // 1x1 k-tiles run, and the epilogue below is stores only (it used to start with an exposed round trip and then
+      // wait, per row sub-tile, for the next residuals behind the stores just issued -- vmcnt retires in order)
+      const int ls = l0 + wm * 64 + tm * 16 + (lane & 15);
+      acc[tn][tm] = *reinterpret_cast<const f32x4*>(d.b1 + n) +
+                    *reinterpret_cast<const f32x4*>(d.X + seq_off + (long)min(ls, d.L - 1) * C + n);
     }
   }
 
@@ -397,28 +402,16 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
       for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
   }
 
-  // ---- + bias + residual -> x' (fp32) and act_next(x') planes
-  // x' overwrites x in place (out_f32 == X), so the compiler must keep every residual load behind the stores that
-  // precede it in program order: the residuals of row sub-tile tm+1 are therefore loaded BEFORE the stores of tm --
-  // one exposed memory round trip per sub-tile pair instead of one per 16-byte store.
-  f32x4 res[4], nres[4];
-  auto load_res = [&](int tm, f32x4 (&r)[4]) {
-    const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
-    const long rowoff = seq_off + (long)min(l, d.L - 1) * C;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) r[tn] = *reinterpret_cast<const f32x4*>(d.X + rowoff + wn * 64 + tn * 16 + nq);
-  };
-  load_res(0, res);
+  // ---- x' = accumulators (bias + residual + 1x1 conv) -> fp32 (in place over x) and act_next(x') planes
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
-    if (tm + 1 < 4) load_res(tm + 1, nres);
     const int l = l0 + wm * 64 + tm * 16 + (lane & 15);
     const long rowoff = seq_off + (long)l * C;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       if (l >= d.L) continue;
       const int n = wn * 64 + tn * 16 + nq;
-      f32x4 v = acc[tn][tm] + *reinterpret_cast<const f32x4*>(d.b1 + n) + res[tn];
+      const f32x4 v = acc[tn][tm];
       if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
       if (d.out_planes) {
         op16x4 hi;
@@ -434,8 +427,6 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
         *reinterpret_cast<op16x4*>(d.out_planes + rowoff + n) = hi;
       }
     }
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) res[tn] = nres[tn];
   }
 }
 
