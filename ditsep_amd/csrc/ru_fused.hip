@@ -16,6 +16,9 @@
 // leaves the CU.
 #include "igemm.h"
 #include "kernels.h"
+#ifndef RU_DBG
+#define RU_DBG 0  // development ablation builds of ru_fused2: 1 = no k7 MFMAs, 2 = no output stores, 3 = no residual loads
+#endif
 #include <cstdlib>
 
 namespace {
@@ -337,10 +340,15 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
         fa[k] = *reinterpret_cast<const op16x8*>(ach + row * KT + ((fchunk ^ ((row >> 1) & 3)) * 8));
         fw[k] = *reinterpret_cast<const op16x8*>(wb + w_frag + k * 16 * KT);
       }
+#if RU_DBG == 1
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(fa[k]), "v"(fw[k]));
+#else
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
+#endif
       if (++st == NSTW) st = 0;
     }
   }
@@ -374,8 +382,12 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
       // 1x1 k-tiles run, and the epilogue below is stores only (it used to start with an exposed round trip and then
       // wait, per row sub-tile, for the next residuals behind the stores just issued -- vmcnt retires in order)
       const int ls = l0 + wm * 64 + tm * 16 + (lane & 15);
+#if RU_DBG == 3
+      acc[tn][tm] = *reinterpret_cast<const f32x4*>(d.b1 + n);
+#else
       acc[tn][tm] = *reinterpret_cast<const f32x4*>(d.b1 + n) +
                     *reinterpret_cast<const f32x4*>(d.X + seq_off + (long)min(ls, d.L - 1) * C + n);
+#endif
     }
   }
 
@@ -412,6 +424,10 @@ __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const
       if (l >= d.L) continue;
       const int n = wn * 64 + tn * 16 + nq;
       const f32x4 v = acc[tn][tm];
+#if RU_DBG == 2
+      asm volatile("" ::"v"(v));
+      continue;
+#endif
       if (d.out_f32) *reinterpret_cast<f32x4*>(d.out_f32 + rowoff + n) = v;
       if (d.out_planes) {
         op16x4 hi;
