@@ -16,6 +16,9 @@
 // leaves the CU.
 #include "igemm.h"
 #include "kernels.h"
+#ifndef RU_STAGGER
+#define RU_STAGGER 0
+#endif
 #ifndef RU_DBG
 #define RU_DBG 0  // development ablation builds of ru_fused2: 1 = no k7 MFMAs, 2 = no output stores, 3 = no residual loads
 #endif
@@ -256,6 +259,12 @@ constexpr int LDS2_ELEMS = H_ELEMS + 2 * WTILE;  // 80 KB
 template <int F16>
 __global__ __launch_bounds__(512, 4) void ru_fused2_kernel(const RuDesc d, const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];
+#if RU_STAGGER > 0
+  // development: delay the second resident workgroup of every CU in the first round (workgroup ids 256..511) by about
+  // half a tile, so that the two workgroups of a CU alternate between their k loops and their store phases
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < RU_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int halo = 3 * d.dil;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
