@@ -303,37 +303,71 @@ __global__ void repeat_sources_kernel(const float* __restrict__ y, float* __rest
 // Residual-stream update fused with the next LayerNorm: x[row] += bias + sum of the split-K
 // partial slabs of the preceding GEMM (written back when any were added), then LayerNorm
 // (or a plain copy) to operand planes.  One wave per row, the row lives in registers.
-// NS = number of slabs at compile time: every load of a row (x, bias, all slabs) is issued before the first add,
-// one memory round trip instead of one per slab.
-template <int MAXV, int NS>
-__global__ void residual_norm_kernel(float* __restrict__ x, const float* __restrict__ slabs, int nslab,
-                                     long slab_stride, const float* __restrict__ bias,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     op16_t* __restrict__ out, long ps, int planes, int rows, int D, float eps,
-                                     int do_norm, unsigned char* __restrict__ o8s) {
+// NS = number of slabs at compile time: every load of a quad (x, bias, all slabs) is issued before the first add.
+// BATCH (few rows: single mixtures, where the kernel is one latency chain): x, bias and the slabs of ALL the lane's quads
+// are issued before the first add, the sums are written back after the last load, and gamma / beta of all quads are
+// requested before the reductions start -- about three memory round trips per row where the quad-by-quad form takes
+// twelve (its in-place store of quad k keeps the loads of quad k+1 behind it).  It needs up to 256 VGPRs, which costs
+// the bandwidth-bound large-M case occupancy (M = 2112: 18.8 vs 15.9 us), hence the switch.
+template <int MAXV, int NS, bool BATCH = false>
+__global__ __launch_bounds__(TPB) void residual_norm_kernel(float* __restrict__ x, const float* __restrict__ slabs,
+                                                            int nslab, long slab_stride, const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, op16_t* __restrict__ out,
+                                                            long ps, int planes, int rows, int D, float eps, int do_norm,
+                                                            unsigned char* __restrict__ o8s) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int nv = D >> 2;
   for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
     const long rbase = (long)row * D;
     f32x4 v[MAXV];
+    f32x4 gq[BATCH ? MAXV : 1], bq[BATCH ? MAXV : 1];
     float s = 0.f;
+    if constexpr (BATCH) {
+      f32x4 bv[MAXV];
+      f32x4 part[NS > 0 ? NS : 1][MAXV];
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int i = lane + k * 64;
-      if (i < nv) {
-        f32x4 a = reinterpret_cast<const f32x4*>(x + rbase)[i];
-        if (NS > 0) {
-          f32x4 part[NS > 0 ? NS : 1];
+      for (int k = 0; k < MAXV; ++k) {
+        const int i = min(lane + k * 64, nv - 1);  // clamped: lanes past the row re-read its last quad, never stored
+        v[k] = reinterpret_cast<const f32x4*>(x + rbase)[i];
+        bv[k] = (NS > 0 && bias) ? reinterpret_cast<const f32x4*>(bias)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int z = 0; z < NS; ++z) part[z] = reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
-          if (bias) a += reinterpret_cast<const f32x4*>(bias)[i];
+        for (int z = 0; z < NS; ++z) part[z][k] = reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
+      }
 #pragma unroll
-          for (int z = 0; z < NS; ++z) a += part[z];
-          reinterpret_cast<f32x4*>(x + rbase)[i] = a;
+      for (int k = 0; k < MAXV; ++k) {
+        const int i = lane + k * 64;
+        if (do_norm) {
+          gq[k] = reinterpret_cast<const f32x4*>(gamma)[min(i, nv - 1)];
+          bq[k] = beta ? reinterpret_cast<const f32x4*>(beta)[min(i, nv - 1)] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        v[k] = a;
-        s += (a[0] + a[1]) + (a[2] + a[3]);
+        v[k] += bv[k];
+#pragma unroll
+        for (int z = 0; z < NS; ++z) v[k] += part[z][k];
+        if (i < nv) {
+          if (NS > 0) reinterpret_cast<f32x4*>(x + rbase)[i] = v[k];
+          s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int i = lane + k * 64;
+        if (i < nv) {
+          f32x4 a = reinterpret_cast<const f32x4*>(x + rbase)[i];
+          if (NS > 0) {
+            f32x4 part[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int z = 0; z < NS; ++z) part[z] = reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
+            if (bias) a += reinterpret_cast<const f32x4*>(bias)[i];
+#pragma unroll
+            for (int z = 0; z < NS; ++z) a += part[z];
+            reinterpret_cast<f32x4*>(x + rbase)[i] = a;
+          }
+          v[k] = a;
+          s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
       }
     }
     float mean = 0.f, rstd = 1.f;
@@ -359,10 +393,15 @@ __global__ void residual_norm_kernel(float* __restrict__ x, const float* __restr
       if (i < nv) {
         f32x4 o = v[k];
         if (do_norm) {
-          const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+          if constexpr (BATCH) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * g[r];
-          if (beta) o += reinterpret_cast<const f32x4*>(beta)[i];
+            for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * gq[k][r] + bq[k][r];
+          } else {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * g[r];
+            if (beta) o += reinterpret_cast<const f32x4*>(beta)[i];
+          }
         }
         if (o8s) {
           // fp8 (MX) output: a 32-column scale block = the quads of 8 consecutive lanes (nv % 8 == 0: whole groups)
@@ -878,25 +917,27 @@ void launch_repeat_sources(const float* y, float* x, int B, int n, int D, int T,
 void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_stride, const float* bias,
                           const float* gamma, const float* beta, op16_t* out, long ps, int planes, int rows, int D,
                           float eps, int do_norm, hipStream_t st, unsigned char* o8s) {
-#define RN_LAUNCH(MV, NS_)                                                                                       \
-  hipLaunchKernelGGL((residual_norm_kernel<MV, NS_>), dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab, \
+#define RN_LAUNCH(MV, NS_, BT_)                                                                                       \
+  hipLaunchKernelGGL((residual_norm_kernel<MV, NS_, BT_>), dim3(grid_for(rows, 4)), dim3(TPB), 0, st, x, slabs, nslab, \
                      slab_stride, bias, gamma, beta, out, ps, planes, rows, D, eps, do_norm, o8s)
-#define RN_SWITCH(MV)                                                                      \
+#define RN_SWITCH(MV, BT_)                                                                 \
   switch (nslab) {                                                                         \
-    case 0: RN_LAUNCH(MV, 0); break;                                                       \
-    case 1: RN_LAUNCH(MV, 1); break;                                                       \
-    case 2: RN_LAUNCH(MV, 2); break;                                                       \
-    case 3: RN_LAUNCH(MV, 3); break;                                                       \
-    case 4: RN_LAUNCH(MV, 4); break;                                                       \
-    case 5: RN_LAUNCH(MV, 5); break;                                                       \
-    case 6: RN_LAUNCH(MV, 6); break;                                                       \
-    case 7: RN_LAUNCH(MV, 7); break;                                                       \
-    default: RN_LAUNCH(MV, 8); break;  /* pick_ksplit caps the split at 8 */               \
+    case 0: RN_LAUNCH(MV, 0, BT_); break;                                                  \
+    case 1: RN_LAUNCH(MV, 1, BT_); break;                                                  \
+    case 2: RN_LAUNCH(MV, 2, BT_); break;                                                  \
+    case 3: RN_LAUNCH(MV, 3, BT_); break;                                                  \
+    case 4: RN_LAUNCH(MV, 4, BT_); break;                                                  \
+    case 5: RN_LAUNCH(MV, 5, BT_); break;                                                  \
+    case 6: RN_LAUNCH(MV, 6, BT_); break;                                                  \
+    case 7: RN_LAUNCH(MV, 7, BT_); break;                                                  \
+    default: RN_LAUNCH(MV, 8, BT_); break;  /* pick_ksplit caps the split at 8 */          \
   }
-  if (D <= 1024) {
-    RN_SWITCH(4)
+  if (D <= 1024 && rows <= 256) {  // latency-bound: whole-row load batches
+    RN_SWITCH(4, true)
+  } else if (D <= 1024) {
+    RN_SWITCH(4, false)
   } else {
-    RN_SWITCH(16)
+    RN_SWITCH(16, false)
   }
 #undef RN_SWITCH
 #undef RN_LAUNCH
