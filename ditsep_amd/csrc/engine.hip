@@ -1091,7 +1091,15 @@ struct dsn_ctx {
       d.in_pad = -1;
       d.in_bstride = (long)S * D;
       d.out_f32 = SC;
-      run(d, st);
+      // N = n_src * latent_dim is ONE 128-column tile: 128-row tiles leave B*T/128 (17 at C2) workgroups walking the
+      // whole K alone; 64-row panels x 8 waves with a 4-stage ring double the workgroups and the loads in flight
+      static const bool po_tile = getenv("DSN_POUT_TILE") != nullptr;
+      if (use_panel && P == 1 && !po_tile && d.N <= 128 && d.M >= 1024) {
+        d.panel_rows = 64;
+        run(d, st, 128);
+      } else {
+        run(d, st);
+      }
     }
     return SC;
   }

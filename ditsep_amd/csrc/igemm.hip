@@ -21,6 +21,9 @@
 #ifndef DSN_SETPRIO
 #define DSN_SETPRIO 0
 #endif
+#ifndef DSN_SKINNY_U
+#define DSN_SKINNY_U 4  // k-steps per load batch of the skinny kernel (development: 8 = the whole K share of a wave at K = 1024)
+#endif
 #ifndef DSN_DBG_MODE
 #define DSN_DBG_MODE 0  // development ablation builds: 1 = no in-loop staging, 2 = no MFMAs, 3 = no epilogue (halo kernel)
 #endif
@@ -1321,7 +1324,7 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const GemmDesc d) {
   // 4 waves per workgroup split its K range (more loads in flight per CU: the kernel is one HBM round trip long);
   // their partial tiles are summed through LDS in wave order (deterministic) by wave 0, which runs the epilogue
   constexpr int KW = 4;
-  constexpr int U = 4;  // k-steps of 32 per load batch (8 was 3x slower at MT = 2: measured)
+  constexpr int U = DSN_SKINNY_U;  // k-steps of 32 per load batch
   __shared__ f32x4 red[KW - 1][2 * MT][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
