@@ -72,6 +72,12 @@ __device__ __forceinline__ void seed_acc(const GemmDesc& d, f32x4 (&acc)[NT][MT]
     }
   }
 }
+// "Touch" a loaded vector in uniform control flow: hipcc then places its s_waitcnt for the load HERE, once.  Left to
+// the first use inside the per-row-sub-tile blocks (divergent: `if (m >= m_end) continue`), every block gets its own
+// s_waitcnt vmcnt(0) -- the skipped path may still have the load in flight -- and since stores retire through the
+// same counter, every block's stores wait for the previous block's to complete.
+__device__ __forceinline__ void dsn_touch(const f32x4& v) { asm volatile("" ::"v"(v)); }
+
 template <int P, int F16, int NT, int MT, int EPI = 0, int LEAN = 0>
 __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
                                              int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
@@ -117,6 +123,14 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
     // operand plane, and summarised per row (mean, M2 of this wave's 64 columns).  Plain row-major [M][N] tensors.
     // The residual x is not read here: the kernel seeded the accumulators with it (C-in of the first MFMAs), so its
     // load latency hides under the first k-tiles and no load has to wait behind the in-place stores below.
+    f32x4 bvec[NT];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const int n = nw0 + tn * 16 + nq;
+      bvec[tn] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) dsn_touch(bvec[tn]);
 #pragma unroll
     for (int tm = 0; tm < MT; ++tm) {
       const int m = mw0 + tm * 16 + (lane & 15);
@@ -125,8 +139,7 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
         const int n = nw0 + tn * 16 + nq;
-        f32x4 v = acc[tn][tm];
-        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        f32x4 v = acc[tn][tm] + bvec[tn];
         acc[tn][tm] = v;
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
         if (n < d.N) {
@@ -172,6 +185,10 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
       const f32x4 cg = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + 16 + nq);
       const f32x4 bv = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 bg = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      dsn_touch(cv);
+      dsn_touch(cg);
+      dsn_touch(bv);
+      dsn_touch(bg);
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) {
         const int m = mw0 + tm * 16 + (lane & 15);
@@ -194,6 +211,40 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
     }
     return;
   }
+  // Everything the store loop would LOAD is fetched here, in uniform control flow (see dsn_touch): the rotary tables
+  // (applied right away, to every row sub-tile) and the bias vectors of the wave's column sub-tiles.
+  constexpr bool ROPE_FIRST = MT <= 2;  // taller wave tiles have no registers for it (they spill): rotary per sub-tile
+  if (ROPE_FIRST && !f_swiglu && f_rope) {
+    // fused QKV epilogue: this wave's 64 columns are one 64-wide head of the q, k or v section; rotary embedding on the
+    // first 32 features (pairs (c, c+16) = accumulator tiles 0 and 1 of the same lane), q pre-scaled by 1/sqrt(dh)
+    const int section = nw0 / d.qkv_D;
+    if (section < 2 && (nw0 & 63) == 0) {  // rotary features live in the first two 16-tiles of a head
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        const int pos = (mw0 + tm * 16 + (lane & 15)) % d.rope_S;  // rows past m_end: any table row, never stored
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + nq);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + nq);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + 16 + nq);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + 16 + nq);
+        const f32x4 x0 = acc[0][tm], x1 = acc[1][tm];
+        acc[0][tm] = x0 * c0 - x1 * s0;
+        acc[1][tm] = x1 * c1 + x0 * s1;
+      }
+    }
+  }
+  constexpr bool BIAS_FIRST = MT <= 4;  // (taller wave tiles -- the 13- and 17-sub-tile panels -- would spill)
+  f32x4 gbias[NT];
+  if constexpr ((LEAN & LEAN_SEEDED) == 0 && BIAS_FIRST) {
+    if (!f_swiglu) {
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        gbias[tn] = (d.bias && n < d.N) ? *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) dsn_touch(gbias[tn]);
+    }
+  }
   float gs[NT];  // GroupNorm partial sums of this lane's 4 channels per column sub-tile
 #pragma unroll
   for (int tn = 0; tn < NT; ++tn) gs[tn] = 0.f;
@@ -206,12 +257,9 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
     const long row_rel = (long)j * d.out_row_elems + d.out_off;
     const long row_abs = (long)b * d.out_bstride + row_rel;
     if (!f_swiglu) {
-      if (f_rope) {
-        // fused QKV epilogue: this wave's 64 columns are one 64-wide head of the q, k or v section;
-        // rotary embedding on the first 32 features (pairs (c, c+16) = accumulator tiles 0 and 1 of the
-        // same lane), q pre-scaled by 1/sqrt(dh)
+      if (!ROPE_FIRST && f_rope) {
         const int section = nw0 / d.qkv_D;
-        if (section < 2 && (nw0 & 63) == 0) {   // rotary features live in the first two 16-tiles of a head
+        if (section < 2 && (nw0 & 63) == 0) {
           const int pos = m % d.rope_S;
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(d.rope_cos + pos * 32 + nq);
           const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.rope_sin + pos * 32 + nq);
@@ -231,7 +279,8 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
         const long off = row_abs + n;
         f32x4 v = acc[tn][tm];
         if constexpr ((LEAN & LEAN_SEEDED) == 0) {
-          if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+          if constexpr (BIAS_FIRST) v += gbias[tn];
+          else if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
           if (f_qkv && n < d.qkv_D) v *= d.q_scale;  // fused q|k|v projection: q (bias included) pre-scaled
           if (f_bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
           if (d.resid)
