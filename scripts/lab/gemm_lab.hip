@@ -488,6 +488,48 @@ float run_cfg(const char* name, Bufs& b, int M, int N, int K, int panel_rows, in
   return (float)us;
 }
 
+// alternate two different kernels (FF-in, QKV) the way the pipeline does: instruction cache, scalar cache and L2
+// contents change hands at every launch; optionally a small writer kernel touches A in between (A freshly produced)
+static void run_mix(Bufs& b, int M, int iters, int refill) {
+  auto k1 = lab_kernel<4, 4, 17, 4, 64, 2, 0, 1>;
+  auto k2 = lab_kernel<4, 4, 7, 4, 64, 3, 0, 0>;
+  const size_t sm1 = (size_t)2 * (17 * 16 + 256) * 64 * 2, sm2 = (size_t)3 * (7 * 16 + 256) * 64 * 2;
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  Prob d1, d2;
+  d1.A = b.A; d1.C = b.C; d1.M = M; d1.N = 8192; d1.K = 1024; d1.panel_rows = 264; d1.tiles_m = 8; d1.tiles_n = 32;
+  d1.m_fast = 1; d1.pf_mode = 0; d1.stamps = b.stamps; d1.wnext_bytes = 0;
+  d2 = d1; d2.N = 3072; d2.panel_rows = 104; d2.tiles_m = (M + 103) / 104; d2.tiles_n = 12;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 3; ++mode) {  // 0: k1 only, 1: k2 only, 2: alternating
+    CHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) {
+      d1.W = b.W[i % b.rot]; d1.Wnext = d1.W;
+      d2.W = b.W[(i + 7) % b.rot]; d2.Wnext = d2.W;
+      if (refill) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+      if (mode != 1) hipLaunchKernelGGL(k1, dim3(256), dim3(1024), sm1, 0, d1, b.zero);
+      if (refill && mode == 2) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 77 + i);
+      if (mode != 0) hipLaunchKernelGGL(k2, dim3(252), dim3(1024), sm2, 0, d2, b.zero);
+    }
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("mix refill %d mode %d (%s): %.2f us per iteration\n", refill, mode, mode == 0 ? "ffin only" : mode == 1 ? "qkv only" : "ffin+qkv alternating", 1e3 * ms / iters);
+  }
+  if (refill) {
+    CHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("mix: writer kernel alone %.2f us\n", 1e3 * ms / iters);
+  }
+}
+
 static std::vector<unsigned short> g_ref;  // output of the last baseline run (for checking new kernels)
 static void snapshot(const Bufs& b, long n, std::vector<unsigned short>& out) {
   out.resize((size_t)n);
@@ -572,7 +614,7 @@ float run_pp(const char* name, Bufs& b, int M, int N, int K, int panel_rows, int
 
 int main(int argc, char** argv) {
   const int M = 2112;
-  const int iters = 48;
+  const int iters = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 48;
   const int NW = 64;  // weight buffers (16.8 MB each: 1 GB)
   Bufs b;
   const long maxA = (long)M * 4096, maxW = 8192L * 1024, maxC = (long)M * 8192;
@@ -596,6 +638,11 @@ int main(int argc, char** argv) {
 #define RUN(tag, WM, WN, MT, NTW, BK, NST, MODE, SW, M_, N_, K_, PR) \
   if (want(tag)) run_cfg<WM, WN, MT, NTW, BK, NST, MODE, SW>(tag, b, M_, N_, K_, PR, iters);
 
+  if (want("mix")) {
+    b.rot = 64;
+    run_mix(b, M, iters, 0);
+    run_mix(b, M, iters, 1);
+  }
   b.pf = 0;
 #define PP(tag, MT, NST, SW, M_, N_, K_, PR, CHECK) \
   if (want(tag)) run_pp<MT, NST, SW>(tag, b, M_, N_, K_, PR, iters, CHECK);
