@@ -508,20 +508,38 @@ static void run_mix(Bufs& b, int M, int iters, int refill) {
     for (int i = 0; i < iters; ++i) {
       d1.W = b.W[i % b.rot]; d1.Wnext = d1.W;
       d2.W = b.W[(i + 7) % b.rot]; d2.Wnext = d2.W;
-      if (refill) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+      if (refill == 1) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+      if (refill == 2) fill_kernel<<<2048, 256>>>(b.C, (long)M * 8192, 1 + i);  // 35 MB streamed: an HBM-bound neighbour
       if (mode != 1) hipLaunchKernelGGL(k1, dim3(256), dim3(1024), sm1, 0, d1, b.zero);
-      if (refill && mode == 2) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 77 + i);
+      if (refill == 1 && mode == 2) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 77 + i);
+      if (refill == 2 && mode == 2) fill_kernel<<<2048, 256>>>(b.C, (long)M * 8192, 77 + i);
       if (mode != 0) hipLaunchKernelGGL(k2, dim3(252), dim3(1024), sm2, 0, d2, b.zero);
     }
     CHK(hipEventRecord(e1, 0));
     CHK(hipEventSynchronize(e1));
     float ms = 0;
     CHK(hipEventElapsedTime(&ms, e0, e1));
-    printf("mix refill %d mode %d (%s): %.2f us per iteration\n", refill, mode, mode == 0 ? "ffin only" : mode == 1 ? "qkv only" : "ffin+qkv alternating", 1e3 * ms / iters);
+    double mghz = 0;
+    {  // shader clock inside the k loop of the last launch (median over workgroups)
+      const int grid = mode == 1 ? 252 : 252;
+      std::vector<unsigned long long> st((size_t)grid * 4);
+      CHK(hipMemcpy(st.data(), b.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> ghz;
+      for (int g = 0; g < grid; ++g) {
+        const double dc = (double)(st[g * 4 + 2] - st[g * 4 + 0]), dr = (double)(st[g * 4 + 3] - st[g * 4 + 1]);
+        if (dr > 0) ghz.push_back(dc / dr * 0.1);
+      }
+      std::sort(ghz.begin(), ghz.end());
+      if (!ghz.empty()) mghz = ghz[ghz.size() / 2];
+    }
+    printf("mix refill %d mode %d (%s): %.2f us per iteration, last k loop @ %.2f GHz\n", refill, mode, mode == 0 ? "ffin only" : mode == 1 ? "qkv only" : "ffin+qkv alternating", 1e3 * ms / iters, mghz);
   }
   if (refill) {
     CHK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+    for (int i = 0; i < iters; ++i) {
+      if (refill == 1) fill_kernel<<<256, 256>>>(b.A, (long)M * 1024, 1 + i);
+      else fill_kernel<<<2048, 256>>>(b.C, (long)M * 8192, 1 + i);
+    }
     CHK(hipEventRecord(e1, 0));
     CHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -642,6 +660,7 @@ int main(int argc, char** argv) {
     b.rot = 64;
     run_mix(b, M, iters, 0);
     run_mix(b, M, iters, 1);
+    run_mix(b, M, iters, 2);
   }
   b.pf = 0;
 #define PP(tag, MT, NST, SW, M_, N_, K_, PR, CHECK) \
