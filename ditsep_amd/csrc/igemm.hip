@@ -245,9 +245,14 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
       for (int tn = 0; tn < NT; ++tn) dsn_touch(gbias[tn]);
     }
   }
-  float gs[NT];  // GroupNorm partial sums of this lane's 4 channels per column sub-tile
+  // GroupNorm slice partials in ONE pass over the accumulators, so that a sub-tile's registers are free once it is stored
+  // (a second, deviation pass kept all 64 alive across the store loop: 60 spilled registers in the 128-VGPR halo kernel).
+  // Per lane and column sub-tile: shifted sums about the lane's first value K (sum (v-K), sum (v-K)^2 -- no cancellation,
+  // K sits inside the data), turned into (mean, M2) of the lane's MT x 4 values and merged over the 16 row lanes with
+  // Chan's pairwise formula in a fixed xor tree.
+  float gk[NT], gs1[NT], gs2[NT];
 #pragma unroll
-  for (int tn = 0; tn < NT; ++tn) gs[tn] = 0.f;
+  for (int tn = 0; tn < NT; ++tn) gk[tn] = gs1[tn] = gs2[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
     const int m = mw0 + tm * 16 + (lane & 15);
@@ -289,8 +294,13 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
         }
         v *= d.out_scale;
         if (f_gn) {
-          gs[tn] += (v[0] + v[1]) + (v[2] + v[3]);
-          acc[tn][tm] = v;  // kept for the second (deviation) pass below
+          if (tm == 0) gk[tn] = v[0];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dl = v[r] - gk[tn];
+            gs1[tn] += dl;
+            gs2[tn] += dl * dl;
+          }
         }
         if (d.out_f32) {
           f32x4 o = v;
@@ -389,28 +399,24 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
     }
   }
   if (f_gn && mw0 < m_end) {
-    // the wave's rows are one whole 64-row slice of one item (rows_per_b % 64 == 0): per (column sub-tile, 4-channel
-    // lane group) mean over the 16 row lanes x MT sub-tiles x 4 channels, then the squared deviations, one plain
-    // store per quad -- no atomics, every launch writes the same bits
+    // the wave's rows are one whole 64-row slice of one item (rows_per_b % 64 == 0, so no row of it is masked): one
+    // plain store per (slice, quad) -- no atomics, every launch writes the same bits
     const int b = mw0 / d.rows_per_b;
     const int slice = (mw0 - b * d.rows_per_b) >> 6;
     const int S = d.rows_per_b >> 6;
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) {
-      float s = gs[tn];
+      float cnt = (float)(MT * 4);
+      float mean = gk[tn] + gs1[tn] / cnt;
+      float m2 = gs2[tn] - gs1[tn] * gs1[tn] / cnt;
 #pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-      const float mean = s * (1.f / (MT * 64));
-      float m2 = 0.f;
-#pragma unroll
-      for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dl = acc[tn][tm][r] - mean;
-          m2 += dl * dl;
-        }
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+      for (int o = 8; o >= 1; o >>= 1) {  // equal-count merge: mean' = (mA + mB)/2, M2' = M2A + M2B + (mB - mA)^2 n/2
+        const float om = __shfl_xor(mean, o, 64), o2 = __shfl_xor(m2, o, 64);
+        const float dm = om - mean;
+        m2 = m2 + o2 + dm * dm * (0.5f * cnt);
+        mean = 0.5f * (mean + om);
+        cnt *= 2.f;
+      }
       const int n = nw0 + tn * 16 + nq;
       if ((lane & 15) == 0 && n < d.N)
         *reinterpret_cast<float2*>(d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2) = float2{mean, m2};
