@@ -1503,10 +1503,8 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
 }
 
 // halo-resident 3x3 conv: eligibility + launch (hipErrorNotSupported = not eligible, caller falls back)
-// MINW = 4: registers capped at 128 so that two 8-wave workgroups share a CU (grids of >= 2 workgroups per CU: the
-// epilogue spills ~60 registers but the pair hides each other's barriers); MINW = 1: uncapped (162 VGPRs, one workgroup
-// per CU) for grids that cannot put two on a CU anyway.  Measured (C2 batch): level 0 (512 workgroups) 91 vs 101 us,
-// level 1 (256 workgroups) 88 vs 80 us.
+// MINW = 4: registers capped at 128 so that two 8-wave workgroups share a CU (123 VGPRs, no spills since the GroupNorm
+// partials are taken in one pass); MINW = 1 for the 4-wave 128-row variant.
 template <int F16, int TBM, int MINW>
 static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = d.M / TBM;
@@ -1536,7 +1534,9 @@ hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream)
   const long wgs = (long)(d.M / 256) * cdiv(d.N, 128);
   if (wgs >= 2 * 256)  // MI355X: 256 CUs
     return f16 ? launch_halo_t<1, 256, 4>(d, zp, stream) : launch_halo_t<0, 256, 4>(d, zp, stream);
-  return f16 ? launch_halo_t<1, 256, 1>(d, zp, stream) : launch_halo_t<0, 256, 1>(d, zp, stream);
+  // fewer than two 256-row workgroups per CU (NCSN++ level 1: 256): 128-row tiles of 4 waves, two of them per CU
+  // (whole score call 5.48 -> 5.38 ms)
+  return f16 ? launch_halo_t<1, 128, 1>(d, zp, stream) : launch_halo_t<0, 128, 1>(d, zp, stream);
 }
 
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
