@@ -383,8 +383,11 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
   }
   const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);
   if (nkt <= 4) {
-    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, nkt), dim3(64), sm, st, qkv, ps, out, out_ps,
-                       S, H, o8s);
+    // waves per workgroup: each takes one query tile of the same (item, head) and they stage V once
+    static const char* wenv = getenv("DSN_ATTN_W");
+    const int W = wenv ? std::max(1, std::min(4, atoi(wenv))) : 3;  // measured at S = 33 (3 query tiles): 12.9 / 12.6 / 12.3 / 12.5 us for 1..4
+    hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 4, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sm, st, qkv,
+                       ps, out, out_ps, S, H, o8s);
   } else {
     static std::atomic<unsigned long long> attr{0};
     if (dsn_first_use_on_device(attr)) {
