@@ -395,7 +395,12 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // wide heads stage a large V block (DH * nkt * 32 B): share it between the query tiles' waves
-    const int W = DH >= 128 ? (nkt >= 8 ? 8 : (nkt >= 4 ? 4 : 1)) : 1;
+    // the query tiles of an (item, head) share workgroups of up to 8 waves: V is staged once per workgroup (it used to be
+    // one wave per workgroup for 64-wide heads: at S = 236 every one of the 15 query tiles staged the 30 KB of V
+    // again -- 44 -> 23 us per launch at the C5 shape)
+    static const char* wenv16 = getenv("DSN_ATTN_W16");  // development
+    int W = nkt >= 8 ? 8 : (nkt >= 4 ? 4 : 1);
+    if (wenv16) W = std::max(1, std::min(8, atoi(wenv16)));
     hipLaunchKernelGGL((attention_mfma_kernel<P, F16, 16, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sm, st,
                        qkv, ps, out, out_ps, S, H, o8s);
   }
