@@ -238,13 +238,17 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const op16_t* __res
 // accumulator rescaled by exp(m_old - m_new) per block), V staged per block -- registers and LDS no longer grow
 // with S.  One wave per (item, head, 16-query tile).
 template <int P, int F16, int DH>
-__global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __restrict__ qkv, long ps,
+__global__ __launch_bounds__(512) void attention_long_kernel(const op16_t* __restrict__ qkv, long ps,
                                                             op16_t* __restrict__ out, long out_ps, int S, int H,
                                                             unsigned char* __restrict__ o8s) {
   constexpr int KBT = 8;         // key tiles per block
   constexpr int KB = KBT * 16;   // keys per block
   extern __shared__ __attribute__((aligned(16))) op16_t vlds[];  // [P][KB][DH]
-  const int lane = threadIdx.x;
+  // blockDim.x / 64 waves per workgroup: each owns one query tile, all walk the key blocks together and stage each
+  // V block once (one wave per workgroup staged the 64 KB block of a 256-wide head alone: 260 us per launch at 944
+  // tokens)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * DH;
   const long rs = 3L * D;
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __rest
   constexpr int KSD = DH / 32, NDT = DH / 16, CPRV = DH / 8;
   const op16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  for (int qt = blockIdx.y; qt < nqt; qt += gridDim.y) {
+  for (int qt0 = blockIdx.y * nwaves; qt0 < nqt; qt0 += gridDim.y * nwaves) {
+    const int qt = qt0 + wave;  // waves past the last query tile run along (barriers, staging) and store nothing
     const int qrow = min(qt * 16 + r16, S - 1);
     op16x8 fq[P][KSD];
 #pragma unroll
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(64) void attention_long_kernel(const op16_t* __rest
 
     for (int k0 = 0; k0 < S; k0 += KB) {
       __syncthreads();  // the previous block's V reads are done
-      for (int idx = lane; idx < KB * CPRV; idx += 64) {
+      for (int idx = threadIdx.x; idx < KB * CPRV; idx += blockDim.x) {
         const int row = idx / CPRV, c = idx % CPRV;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -377,8 +382,10 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<P, F16, DH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, nkt), dim3(64), sml, st, qkv, ps, out, out_ps, S,
-                       H, o8s);
+    static const char* wl = getenv("DSN_ATTN_WL");  // development
+    const int W = wl ? std::max(1, std::min(8, atoi(wl))) : 8;
+    hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sml, st, qkv, ps,
+                       out, out_ps, S, H, o8s);
     return;
   }
   const size_t sm = (size_t)P * nkt * 16 * DH * sizeof(op16_t);

@@ -8,7 +8,8 @@ ncfg = synthetic.NCSNppConfig()
 nsd = synthetic.random_ncsnpp_weights(ncfg, 1)
 eng = make_engine(ncfg=ncfg, nsd=nsd, precision=int(os.environ.get("PREC", "3")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-xt = torch.randn(B, 2, 64, 32, device="cuda"); mix = torch.randn(B, 1, 64, 32, device="cuda"); t = torch.full((B,), 0.5, device="cuda")
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+xt = torch.randn(B, 2, 64, T, device="cuda"); mix = torch.randn(B, 1, 64, T, device="cuda"); t = torch.full((B,), 0.5, device="cuda")
 for _ in range(3): out = eng.score(xt, t, mix)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): eng.score(xt, t, mix)

@@ -7,8 +7,8 @@ from tests.util import make_engine
 ncfg = synthetic.NCSNppConfig()
 nsd = synthetic.random_ncsnpp_weights(ncfg, 1)
 eng = make_engine(ncfg=ncfg, nsd=nsd, precision=int(os.environ.get("PREC", "3")))
-dev = torch.device("cuda"); B = 64
-xt = torch.randn(B, 2, 64, 32, device=dev); mix = torch.randn(B, 1, 64, 32, device=dev); t = torch.full((B,), 0.5, device=dev)
+dev = torch.device("cuda"); B = int(os.environ.get("B", "64")); T = int(os.environ.get("T", "32"))
+xt = torch.randn(B, 2, 64, T, device=dev); mix = torch.randn(B, 1, 64, T, device=dev); t = torch.full((B,), 0.5, device=dev)
 for _ in range(3):
     eng.score(xt, t, mix)
 torch.cuda.synchronize()
