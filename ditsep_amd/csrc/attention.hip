@@ -383,7 +383,7 @@ void launch_t(const op16_t* qkv, long ps, op16_t* out, long out_ps, int B, int S
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     static const char* wl = getenv("DSN_ATTN_WL");  // development
-    const int W = wl ? std::max(1, std::min(8, atoi(wl))) : 8;
+    const int W = wl ? std::max(1, std::min(8, atoi(wl))) : 4;  // measured (1 / 2 / 4 / 8): NCSN++ 944 tokens 7.48 / 7.17 / 7.14 / 7.31 ms per call, DiT 301 tokens 32.5 / 26.5 / 23.4 / 25.0 us
     hipLaunchKernelGGL((attention_long_kernel<P, F16, DH>), dim3(B * H, (nkt + W - 1) / W), dim3(64 * W), sml, st, qkv, ps,
                        out, out_ps, S, H, o8s);
     return;
