@@ -719,6 +719,37 @@ struct dsn_ctx {
       HIPCHK(hipEventRecord(pr.a, st));
     }
     static const bool use_v1 = getenv("DSN_IGEMM_V1") != nullptr;
+    // NCSN++ convs of single mixtures: a handful of 128 x 128 tiles each walking a long K alone -> split-K over enough
+    // workgroups for a quarter of the chip, then the slab epilogue (B = 1, T = 16: score call 3.07 -> see DESIGN 5)
+    static const bool no_csplit = getenv("DSN_NO_CONV_SPLIT") != nullptr;
+    const long ctiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+    if (!no_csplit && P == 1 && cfg.score_kind == DSN_SCORE_NCSNPP && !skinny && panel_bn == 0 && d.ksplit <= 1 &&
+        d.Cin % 32 == 0 && d.N % 64 == 0 && ctiles <= 32 && d.taps * d.Cin >= 512 && !d.swiglu && !d.rope_cos &&
+        (d.out_f32 || d.out_planes) && d.out_off >= 0 && d.tap_dil >= 0 && d.in_stride == 1 &&
+        (d.img_w > 0 || (d.taps == 1 && d.in_pad == 0))) {
+      const int nkt = d.taps * d.Cin / 32;
+      const int ks = (int)std::max(2L, std::min<long>(std::min<long>(8, nkt / 4), 64 / ctiles));
+      const long span = (long)cdiv(d.M, d.rows_per_b) * d.out_bstride;  // floats one slab covers: the output view
+      float* slabs = wsbuf<float>("conv_slabs", span * 8);
+      GemmDesc g = d;
+      g.ksplit = ks;
+      g.slab_stride = span;
+      g.out_f32 = slabs;
+      g.out_planes = nullptr;
+      g.gn_stats = nullptr;
+      g.cfg_bm = 128;
+      g.cfg_bn = 128;
+      g.cfg_nst = 3;
+      g.cfg_bk = 32;
+      hipError_t e1 = igemm2_launch(g, PL, st);
+      if (e1 == hipSuccess) e1 = igemm_slab_epilogue_launch(d, PL, slabs, ks, span, st);
+      if (profiling) {
+        HIPCHK(hipEventRecord(pr.b, st));
+        prof.push_back(pr);
+      }
+      if (e1 != hipSuccess) fail(DSN_EHIP, "split conv launch failed: %s", hipGetErrorString(e1));
+      return;
+    }
     hipError_t e = skinny ? igemm_skinny_launch(d, PL, st)
                           : (panel_bn > 0 ? igemm_panel_launch(d, PL, panel_bn, st)
                                           : ((use_v1 && d.ksplit <= 1) ? igemm_launch(d, PL, st) : igemm2_launch(d, PL, st)));

@@ -103,6 +103,10 @@ struct GemmDesc {
 hipError_t igemm_launch(const GemmDesc& d, int pl, hipStream_t stream);   // v1: register-staged
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream);  // v2: glds ring + split-K, auto tile
 hipError_t igemm2_launch_cfg(const GemmDesc& d, int pl, int bm, int bn, int nstage, int bk, hipStream_t stream);
+// sums `nslab` split-K slabs (written by a GEMM launched with d.ksplit = nslab, d.out_f32 = slabs) and runs the ordinary
+// epilogue of `d` on the result (single-plane modes, N % 64 == 0)
+hipError_t igemm_slab_epilogue_launch(const GemmDesc& d, int pl, const float* slabs, int nslab, long slab_stride,
+                                      hipStream_t stream);
 // halo-resident 3x3 conv (single-plane modes, W <= 32, H*W % 256 == 0); hipErrorNotSupported when not eligible
 hipError_t igemm_halo3x3_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // `pl` = DSN_PL(plane count, fp16 flag)

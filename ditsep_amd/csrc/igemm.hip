@@ -1539,6 +1539,65 @@ hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream)
   return f16 ? launch_halo_t<1, 128, 1>(d, zp, stream) : launch_halo_t<0, 128, 1>(d, zp, stream);
 }
 
+// Split-K for conv GEMMs whose output tiles fill only a fraction of the chip (single mixtures: a 3x3 conv of the NCSN++
+// level 0 is 8 tiles): the GEMM writes raw partial sums to `nslab` slabs (GemmDesc::ksplit), this kernel sums them in
+// slab order into the accumulator layout -- one wave per 64 x 64 tile, bias / per-item bias / residual fetched with the
+// slabs (seed_acc) -- and runs the ordinary epilogue (scale, GroupNorm partials, fp32 / plane outputs): one code path
+// for both, deterministic.  (At the C2 batch the pass costs 18-21 us and loses against the unsplit GEMM; it is used
+// for small grids only.)
+namespace {
+template <int F16>
+__global__ __launch_bounds__(64) void igemm_slab_epilogue_kernel(GemmDesc d, const float* __restrict__ slabs, int nslab,
+                                                                 long slab_stride) {
+  const int lane = threadIdx.x & 63;
+  const int tiles_n = (d.N + 63) >> 6;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int mw0 = tile_m * 64, nw0 = tile_n * 64;
+  const int nq = (lane >> 4) * 4;
+  f32x4 acc[4][4];
+  long offs[4];
+  bool rowok[4];
+  seed_acc<4, 4>(d, acc, mw0, d.M, nw0, lane);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = mw0 + tm * 16 + (lane & 15);
+    const bool mok = m < d.M;
+    const int b = mok ? m / d.rows_per_b : 0;
+    const int j = mok ? m - b * d.rows_per_b : 0;
+    const long row_rel = (long)j * d.out_row_elems + d.out_off;
+    offs[tm] = (long)b * d.out_bstride + row_rel;
+    rowok[tm] = mok && row_rel + nw0 >= 0 && row_rel + nw0 + 64 <= d.out_limit;
+  }
+  for (int z = 0; z < nslab; ++z) {
+    f32x4 part[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = nw0 + tn * 16 + nq;
+        part[tn][tm] = (rowok[tm] && n < d.N) ? *reinterpret_cast<const f32x4*>(slabs + z * slab_stride + offs[tm] + n)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tn][tm] += part[tn][tm];
+  }
+  epilogue_gen<1, F16, 4, 4, 0, LEAN_NO_DIT | LEAN_SEEDED>(d, acc, mw0, d.M, nw0, lane, 0);
+}
+}  // namespace
+
+hipError_t igemm_slab_epilogue_launch(const GemmDesc& din, int pl, const float* slabs, int nslab, long slab_stride,
+                                      hipStream_t stream) {
+  if (PL_COUNT(pl) != 1 || din.swiglu || din.rope_cos || nslab < 1 || din.N % 64 != 0) return hipErrorInvalidValue;
+  GemmDesc d = din;
+  d.ksplit = 1;
+  const int grid = cdiv(d.M, 64) * cdiv(d.N, 64);
+  if (PL_F16(pl)) hipLaunchKernelGGL(igemm_slab_epilogue_kernel<1>, dim3(grid), dim3(64), 0, stream, d, slabs, nslab, slab_stride);
+  else hipLaunchKernelGGL(igemm_slab_epilogue_kernel<0>, dim3(grid), dim3(64), 0, stream, d, slabs, nslab, slab_stride);
+  return hipGetLastError();
+}
+
 hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
   const int planes = PL_COUNT(pl);
   // Tile choice from the measured sweeps (scripts/gemm_bench.py; profiles/r01_gemm_sweep_*.log).
