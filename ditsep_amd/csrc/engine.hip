@@ -898,15 +898,15 @@ struct dsn_ctx {
     // folded ff_norm (single-plane modes, panels of at most 80 rows fill whole rounds): to_out runs WITHOUT split-K in
     // 128-column tiles, adds the residual itself and writes x' (fp32), its raw operand plane and per-row statistics;
     // FF-in then applies the LayerNorm algebraically in its epilogue -- the LayerNorm launch between them is gone
-    // single mixtures (up to 64 token rows; DSN_SKINNY_MAX narrows): weight-streaming skinny kernels, split-K 8 for
+    // single mixtures and pairs (up to 80 token rows = 5 sub-tiles; DSN_SKINNY_MAX moves the limit, at most 128): weight-streaming skinny kernels, split-K 8 for
     // the two N = D GEMMs so that every CU streams a share of their weights.  Measured (scripts/score_time.py, one
     // score call): M = 33: 1.52 ms vs 2.27 ms with the panel kernels; M = 17 (config C1): 1.37 vs 2.02 ms; M = 9:
-    // 1.28 vs 2.01 ms; M = 61 (4 sub-tiles): 1.77 vs 2.10 ms.  (The window used to start at 33 rows: below it the launcher picked the 1- / 2-sub-tile
+    // 1.28 vs 2.01 ms; M = 61 (4 sub-tiles): 1.77 vs 2.10 ms; M = 66 (5): 1.72 vs 2.07; M = 99 (7): 2.03 vs 2.08; M = 126 (8): 2.22 vs 2.10.  (The window used to start at 33 rows: below it the launcher picked the 1- / 2-sub-tile
     // instantiations, which run 2.5x slower than the 3-sub-tile one on the same data -- see igemm_skinny_launch.)
     static const bool no_skinny = getenv("DSN_NO_SKINNY") != nullptr;
     const char* skm = getenv("DSN_SKINNY_MIN");  // read per call (tests)
     const char* skx = getenv("DSN_SKINNY_MAX");
-    const int skinny_min = skm ? atoi(skm) : 1, skinny_max = skx ? std::min(atoi(skx), 64) : 64;
+    const int skinny_min = skm ? atoi(skm) : 1, skinny_max = skx ? std::min(atoi(skx), 128) : 80;
     const bool skinny = !no_skinny && P == 1 && !fp8 && M >= skinny_min && M <= skinny_max && D % 256 == 0;
     int fold_rows = 0;
     if (fold_ln && use_panel_ok(D) && !skinny) {

@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const GemmDesc d) {
   // 4 waves per workgroup split its K range (more loads in flight per CU: the kernel is one HBM round trip long);
   // their partial tiles are summed through LDS in wave order (deterministic) by wave 0, which runs the epilogue
   constexpr int KW = 4;
-  constexpr int U = DSN_SKINNY_U;  // k-steps of 32 per load batch
+  constexpr int U = MT <= 4 ? DSN_SKINNY_U : 2;  // k-steps of 32 per load batch (registers: U * (MT + 2) fragments)
   __shared__ f32x4 red[KW - 1][2 * MT][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1708,7 +1708,7 @@ hipError_t igemm_skinny_launch(const GemmDesc& din, int pl, hipStream_t stream) 
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
   if (PL_COUNT(pl) != 1 || d.taps != 1 || d.in_stride != 1 || d.in_pad != 0 || d.rows_per_b != d.M || d.img_w > 0 ||
-      d.M <= 0 || d.M > 64 || d.N <= 0 || d.Cin % 32 != 0 || d.N % 4 != 0 || d.gn_stats || d.stat_out || d.ln_stats ||
+      d.M <= 0 || d.M > 128 || d.N <= 0 || d.Cin % 32 != 0 || d.N % 4 != 0 || d.gn_stats || d.stat_out || d.ln_stats ||
       d.out_fp8)
     return hipErrorInvalidValue;
   if (d.swiglu && d.N % 32 != 0) return hipErrorInvalidValue;
@@ -1725,7 +1725,7 @@ hipError_t igemm_skinny_launch(const GemmDesc& din, int pl, hipStream_t stream) 
     else hipLaunchKernelGGL((igemm_skinny_kernel<0, MT_>), dim3(grid), dim3(256), 0, stream, d);     \
     return hipGetLastError();                                                                       \
   }
-  SK(3) SK(4)
+  SK(3) SK(4) SK(5) SK(6) SK(7) SK(8)
 #undef SK
   return hipErrorInvalidValue;
 }
