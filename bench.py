@@ -27,6 +27,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL on this driver stack shares buffers between ranks through dmabuf IPC only; must be in the environment
+# before the HIP runtime starts, whoever launched the ranks (torch.distributed.run or launch_ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def log(*a):
@@ -116,24 +119,29 @@ def cpu_baseline(dcfg, vcfg, dsd, vsd, y_c2, y_c1):
     score = odit.DiTScore(dsd, dcfg) if isinstance(dcfg, synthetic.DiTConfig) else oncs.NCSNppScore(dsd, dcfg)
     g = torch.Generator().manual_seed(99)
     out = {}
-    for name, y, L, N in (("c2_b1", y_c2, FS * SECONDS, N_STEPS), ("c1", y_c1, 8000 * SECONDS, 10)):
+    for name, y, L, N, reps in (("c2_b1", y_c2[:1], FS * SECONDS, N_STEPS, 4), ("c2_b4", y_c2, FS * SECONDS, N_STEPS, 2),
+                                ("c1", y_c1, 8000 * SECONDS, 10, 4)):
         y = y.detach().cpu().float()
         noise = osmp.draw_noise(g, 1 + N * (CORR + 1), (y.shape[0], dcfg.n_src, vcfg.latent_dim, y.shape[-1]))
         times, wav = [], None
-        for rep in range(4):                      # warm-up + 3
+        for rep in range(reps):                   # warm-up + the timed runs (the batch-4 leg is already warm)
             dt, wav = _cpu_run(score, vsd, vcfg, dcfg, y, noise, L, N)
-            if rep:
+            if rep or name == "c2_b4":
                 times.append(dt)
             log(f"cpu {name} run {rep}: {dt:.2f} s")
         out[name] = dict(times=times, best=min(times), noise=noise, wav=wav, y=y, L=L, N=N)
-    c2, c1 = out["c2_b1"], out["c1"]
+    c2, c4, c1 = out["c2_b1"], out["c2_b4"], out["c1"]
+    nb = c4["y"].shape[0]
     rec = {"value": round(1.0 / c2["best"], 4), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"1 mixture of the C2 workload (16 kHz x 4 s, N=30, 60 NFE, sampler+decode; batch 1), "
                      f"PyTorch-CPU fp32 oracle, 1 warm-up + best of 3: {[round(t, 2) for t in c2['times']]} s",
+           "c2_b4": {"value": round(nb / c4["best"], 4), "unit": "utt/s",
+                     "sample": f"{nb} mixtures of the C2 workload as one batch, sampler+decode, best of 2 (warm): "
+                               f"{[round(t, 2) for t in c4['times']]} s"},
            "c1": {"value": round(1.0 / c1["best"], 4), "unit": "utt/s",
                   "sample": f"config C1 exactly: 8 kHz x 4 s (T=16), N=10 (20 NFE), batch 1, sampler+decode, "
                             f"1 warm-up + best of 3: {[round(t, 2) for t in c1['times']]} s"}}
-    return rec, c2, c1
+    return rec, c4, c1
 
 
 def roofline_rows(prof, fp8_sites=()):
@@ -413,15 +421,25 @@ def main():
                 out["extra"]["c5_long_form"] = measure_c5(eng, dcfg, dev)
         if not args.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
-            cb, c2, c1 = cpu_baseline(dcfg, vcfg, dsd, vsd, y[:1], y1)
+            cb, c2, c1 = cpu_baseline(dcfg, vcfg, dsd, vsd, y[:min(4, B)], y1)
             log("cpu baseline done:", cb["value"], "utt/s on", cb["cores"], "threads")
             out["cpu_baseline"] = cb
             # live parity of the native path on the very samples the CPU just computed
             from oracle import metrics as omet
             par = {}
-            for name, c, s_ref in (("c2_b1", c2, src[:1]), ("c1", c1, None)):
-                xg, _ = eng.pc_sample(c["y"], c["noise"], N=c["N"], corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
-                wg = eng.decode(xg, c["L"]).cpu()
+            nb = c2["y"].shape[0]
+            for name, c, s_ref in (("c2", c2, src[:nb]), ("c1", c1, None)):
+                if name == "c2":
+                    # the kernels the headline times: the oracle's noise rides as items 0..nb-1 of the FULL timed
+                    # batch (mixtures are independent), the other items draw their own; the replayed graph runs
+                    nz = torch.randn((c["noise"].shape[0], B) + tuple(c["noise"].shape[2:]), device=dev)
+                    nz[:, :nb] = c["noise"].to(dev)
+                    xg, _ = eng.pc_sample(y, nz, N=c["N"], corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
+                    wg = eng.decode(xg, c["L"])[:nb].cpu()
+                    del nz
+                else:
+                    xg, _ = eng.pc_sample(c["y"], c["noise"], N=c["N"], corrector_steps=CORR, snr=SNR, t_eps=T_EPS)
+                    wg = eng.decode(xg, c["L"]).cpu()
                 par[name] = float((wg.double() - c["wav"].double()).norm() / c["wav"].double().norm())
                 if s_ref is not None:
                     # BASELINE's second metric: |SI-SDR(build, s) - SI-SDR(CPU path, s)| under PIT against the
@@ -429,10 +447,13 @@ def main():
                     sdr_g, _ = eng.si_sdr_pit(s_ref, wg)
                     sdr_c, _ = omet.si_sdr_pit(s_ref, c["wav"])
                     par["si_sdr_delta_db_vs_cpu_fp32"] = float((sdr_g.mean(-1) - sdr_c).abs().max())
-            out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": par["c2_b1"], "rel_l2_waveform_vs_cpu_fp32_c1": par["c1"],
+            out["parity"] = {"rel_l2_waveform_vs_cpu_fp32": par["c2"], "rel_l2_waveform_vs_cpu_fp32_c1": par["c1"],
                              "tolerance": 1e-3, "si_sdr_delta_db_vs_cpu_fp32": par["si_sdr_delta_db_vs_cpu_fp32"],
-                             "si_sdr_tolerance_db": 0.05, "mixtures": 1,
-                             "note": "2-mixture N=30 chain, C4 and C5 parity: tests/test_gpu_configs.py"}
+                             "si_sdr_tolerance_db": 0.05, "mixtures": nb,
+                             "how": f"items 0..{nb - 1} of the timed batch of {B} (same kernels, same graph as the "
+                                    "timed steps) carry the CPU oracle's latents and injected noise",
+                             "note": "B=64 score call / N=30 chains (DiT and NCSN++), C4, C5 parity: "
+                                     "tests/test_gpu_headline.py, tests/test_gpu_configs.py"}
         if not args.no_alt:
             noise = torch.randn((1 + N_STEPS * (CORR + 1), 4, dcfg.n_src, 64, int(y.shape[-1])), device=dev)
             wa = eng.decode(eng.pc_sample(y[:4], noise, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L)

@@ -709,7 +709,76 @@ struct dsn_ctx {
     k = std::min(k, std::min(8, nkt / 8));
     return std::max(k, 1);
   }
+  // DSN_AUDIT=1 (tests): before a GEMM-family launch, every pointer of its descriptor is checked on the HOST against
+  // the device allocation that contains it (hipMemGetAddressRange), over the exact extent the kernels' guards allow --
+  // the largest (item, row, column) offsets of A, W, the fp32 / plane / slab outputs, residual, bias vectors, GroupNorm
+  // and LayerNorm partials -- plus the shape preconditions the epilogues rely on (GroupNorm partials: whole 64-row
+  // slices of one item per wave tile, N % 4 == 0; halo conv: tiles inside one image).  An out-of-range descriptor is an
+  // error naming the field instead of a GPU memory fault.
+  void audit_span(const char* what, const void* p, long lo_bytes, long hi_bytes, const GemmDesc& d) const {
+    if (!p || hi_bytes <= lo_bytes) return;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess)
+      fail(DSN_EINVAL, "audit: %s = %p is not inside a device allocation (M=%d N=%d Cin=%d taps=%d)", what, p, d.M, d.N,
+           d.Cin, d.taps);
+    const char* b0 = (const char*)base;
+    const char* q = (const char*)p;
+    if (q + lo_bytes < b0 || q + hi_bytes > b0 + size)
+      fail(DSN_EINVAL, "audit: %s spans [%ld, %ld) bytes from its pointer but the allocation holds [%ld, %ld) "
+           "(M=%d N=%d Cin=%d taps=%d rows_per_b=%d)", what, lo_bytes, hi_bytes, (long)(b0 - q), (long)(b0 + size - q),
+           d.M, d.N, d.Cin, d.taps, d.rows_per_b);
+  }
+  void audit_desc(const GemmDesc& d) const {
+    if (d.a_scale) return;  // fp8 descriptors address bytes pairwise: audited by their launcher's shape checks
+    const long nb = cdiv(d.M, d.rows_per_b), rows_last = d.M - (nb - 1) * (long)d.rows_per_b;
+    const long rows_max = nb > 1 ? d.rows_per_b : rows_last;
+    const long e16 = sizeof(op16_t), e32 = sizeof(float);
+    if (d.M <= 0 || d.N <= 0 || d.rows_per_b <= 0) fail(DSN_EINVAL, "audit: empty GEMM");
+    audit_span("A", d.A, 0, ((nb - 1) * d.in_bstride + (long)(d.Lin - 1) * d.in_row_elems + d.Cin + (P - 1) * d.a_ps) * e16, d);
+    audit_span("W", d.W, 0, ((long)d.N * d.taps * d.Cin + (P - 1) * d.w_ps) * e16, d);
+    const long n_out = d.swiglu ? d.N / 2 : d.N;
+    const long rel_hi = std::min<long>(d.out_limit, (rows_max - 1) * (long)d.out_row_elems + d.out_off + n_out);
+    const long out_hi = (nb - 1) * d.out_bstride + rel_hi;
+    const long ks = std::max(d.ksplit, 1);
+    if (d.stat_out) {  // residual-stream producer: plain row-major [M][N]
+      audit_span("out_f32", d.out_f32, 0, (long)d.M * d.N * e32, d);
+      audit_span("out_planes", d.out_planes, 0, ((long)d.M * d.N + (P - 1) * d.out_ps) * e16, d);
+      audit_span("stat_out", d.stat_out, 0, (long)d.M * d.stat_np * 2 * e32, d);
+    } else {
+      audit_span("out_f32", d.out_f32, 0, (out_hi + (ks - 1) * d.slab_stride) * e32, d);
+      audit_span("out_planes", d.out_planes, 0, (out_hi + (P - 1) * d.out_ps) * e16, d);
+    }
+    audit_span("resid", d.resid, 0, ((nb - 1) * d.resid_bstride + (rows_max - 1) * (long)d.resid_row_elems + d.resid_off + d.N) * e32, d);
+    if (d.resid && d.resid_off < 0) fail(DSN_EINVAL, "audit: negative residual offset");
+    audit_span("bias", d.bias, 0, (long)d.bias_mod * e32, d);
+    audit_span("bbias", d.bbias, 0, ((nb - 1) * (long)d.bbias_stride + d.N) * e32, d);
+    if (d.act == DSN_ACT_SNAKE) {
+      audit_span("act_a", d.act_a, 0, (long)d.act_mod * e32, d);
+      audit_span("act_b", d.act_b, 0, (long)d.act_mod * e32, d);
+    }
+    if (d.gn_stats) {
+      if (d.rows_per_b % 64 != 0 || d.N % 4 != 0 || d.M % d.rows_per_b != 0 || d.ksplit > 1)
+        fail(DSN_EINVAL, "audit: GroupNorm partials need whole 64-row slices (rows_per_b=%d M=%d N=%d ksplit=%d)",
+             d.rows_per_b, d.M, d.N, d.ksplit);
+      audit_span("gn_stats", d.gn_stats, 0, nb * (d.rows_per_b / 64) * (long)(d.N / 4) * 2 * e32, d);
+      if (nb * (d.rows_per_b / 64) * (long)(d.N / 4) * 2 > ncs_slot_floats)
+        fail(DSN_EINVAL, "audit: GroupNorm partials overflow their statistics slot");
+    }
+    if (d.ln_stats) {
+      audit_span("ln_stats", d.ln_stats, 0, (long)d.M * d.ln_np * 2 * e32, d);
+      audit_span("ln_colsum", d.ln_colsum, 0, (long)d.N * e32, d);
+    }
+    if (d.rope_cos) {
+      audit_span("rope_cos", d.rope_cos, 0, (long)d.rope_S * 32 * e32, d);
+      audit_span("rope_sin", d.rope_sin, 0, (long)d.rope_S * 32 * e32, d);
+    }
+    if (d.img_w > 0 && (d.rows_per_b != d.img_w * d.img_h || d.taps != 9))
+      fail(DSN_EINVAL, "audit: 2-D conv descriptor with rows_per_b != H*W");
+  }
   void run(const GemmDesc& d, hipStream_t st, int panel_bn = 0, bool skinny = false) {
+    static const bool audit = getenv("DSN_AUDIT") != nullptr;
+    if (audit) audit_desc(d);
     ProfRec pr;
     if (profiling) {
       HIPCHK(hipEventCreate(&pr.a));

@@ -78,9 +78,32 @@ __device__ __forceinline__ void seed_acc(const GemmDesc& d, f32x4 (&acc)[NT][MT]
 // same counter, every block's stores wait for the previous block's to complete.
 __device__ __forceinline__ void dsn_touch(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
+// Issue gap between the last MFMAs of a k loop and the epilogue's first VALU writes ("MFMA operand
+// registers reused too early"): hipcc re-uses the A / B fragment registers of the final MFMAs for epilogue state within
+// a few instructions of issuing them; experiment switch DSN_DRAIN_NOPS (0 = off).
+#ifndef DSN_DRAIN_NOPS
+#define DSN_DRAIN_NOPS 4
+#endif
+__device__ __forceinline__ void dsn_mfma_drain() {
+#if DSN_DRAIN_NOPS > 0
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < DSN_DRAIN_NOPS; ++i) asm volatile("s_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// value of the lane ROT places to the right inside this lane's 16-lane row (wraps round the row)
+template <int ROT>
+__device__ __forceinline__ float dsn_row_ror(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false));
+}
+
 template <int P, int F16, int NT, int MT, int EPI = 0, int LEAN = 0>
 __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)[NT][MT], int mw0, int m_end, int nw0,
                                              int lane, int z, const float* ln_rows = nullptr, int ln_m0 = 0) {
+  dsn_mfma_drain();
   // A private copy (scalarised by the compiler): read through the kernel-argument reference, descriptor fields were
   // re-fetched after every output store -- the vector stores may alias anything as far as the compiler knows -- from a
   // scratch copy of the argument chunk, behind s_waitcnt vmcnt(0): every 16x16 tile's stores waited for the previous
@@ -247,12 +270,12 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
   }
   // GroupNorm slice partials in ONE pass over the accumulators, so that a sub-tile's registers are free once it is stored
   // (a second, deviation pass kept all 64 alive across the store loop: 60 spilled registers in the 128-VGPR halo kernel).
-  // Per lane and column sub-tile: shifted sums about the lane's first value K (sum (v-K), sum (v-K)^2 -- no cancellation,
-  // K sits inside the data), turned into (mean, M2) of the lane's MT x 4 values and merged over the 16 row lanes with
-  // Chan's pairwise formula in a fixed xor tree.
-  float gk[NT], gs1[NT], gs2[NT];
+  // Per lane and column sub-tile a running (mean, M2) pair: every row sub-tile contributes the exact two-pass (mean, M2)
+  // of its 4 values through Chan's update -- no E[x^2] - E[x]^2, no shift value to carry; the 16 row lanes are merged
+  // with the same formula over a fixed rotation tree below.
+  float gmean[NT], gm2[NT];
 #pragma unroll
-  for (int tn = 0; tn < NT; ++tn) gk[tn] = gs1[tn] = gs2[tn] = 0.f;
+  for (int tn = 0; tn < NT; ++tn) gmean[tn] = gm2[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
     const int m = mw0 + tm * 16 + (lane & 15);
@@ -294,12 +317,22 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
         }
         v *= d.out_scale;
         if (f_gn) {
-          if (tm == 0) gk[tn] = v[0];
+          // exact (mean, M2) of the lane's 4 values, merged into the running pair of this column sub-tile with Chan's
+          // update (counts are compile-time constants: 4 tm values so far, 4 new)
+          const float mb = 0.25f * ((v[0] + v[1]) + (v[2] + v[3]));
+          float m2b = 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dl = v[r] - gk[tn];
-            gs1[tn] += dl;
-            gs2[tn] += dl * dl;
+            const float dl = v[r] - mb;
+            m2b += dl * dl;
+          }
+          if (tm == 0) {
+            gmean[tn] = mb;
+            gm2[tn] = m2b;
+          } else {
+            const float dm = mb - gmean[tn];
+            gmean[tn] += dm * (1.f / (float)(tm + 1));
+            gm2[tn] += m2b + dm * dm * (4.f * (float)tm / (float)(tm + 1));
           }
         }
         if (d.out_f32) {
@@ -407,16 +440,19 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) {
       float cnt = (float)(MT * 4);
-      float mean = gk[tn] + gs1[tn] / cnt;
-      float m2 = gs2[tn] - gs1[tn] * gs1[tn] / cnt;
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) {  // equal-count merge: mean' = (mA + mB)/2, M2' = M2A + M2B + (mB - mA)^2 n/2
-        const float om = __shfl_xor(mean, o, 64), o2 = __shfl_xor(m2, o, 64);
-        const float dm = om - mean;
-        m2 = m2 + o2 + dm * dm * (0.5f * cnt);
-        mean = 0.5f * (mean + om);
-        cnt *= 2.f;
+      float mean = gmean[tn], m2 = gm2[tn];
+      // equal-count merge over the 16 row lanes: mean' = (mA + mB)/2, M2' = M2A + M2B + (mB - mA)^2 n/2, partner =
+      // the lane 8, 4, 2, 1 places round the 16-lane row (DPP row rotate: registers only, no LDS-unit permute)
+#define DSN_GN_MERGE(ROT)                                        \
+      {                                                          \
+        const float om = dsn_row_ror<ROT>(mean), o2 = dsn_row_ror<ROT>(m2); \
+        const float dm = om - mean;                              \
+        m2 = m2 + o2 + dm * dm * (0.5f * cnt);                   \
+        mean = 0.5f * (mean + om);                               \
+        cnt *= 2.f;                                              \
       }
+      DSN_GN_MERGE(8) DSN_GN_MERGE(4) DSN_GN_MERGE(2) DSN_GN_MERGE(1)
+#undef DSN_GN_MERGE
       const int n = nw0 + tn * 16 + nq;
       if ((lane & 15) == 0 && n < d.N)
         *reinterpret_cast<float2*>(d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2) = float2{mean, m2};

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# every GEMM-family launch of the test run is bounds-audited on the host before it is enqueued
+# (csrc/engine.hip::audit_desc): a descriptor that could reach outside its allocations fails by name, not as a GPU fault
+os.environ.setdefault("DSN_AUDIT", "1")
 
 
 def pytest_configure(config):
