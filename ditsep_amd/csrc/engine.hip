@@ -1035,6 +1035,19 @@ struct dsn_ctx {
     };
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
     const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : (short_panel ? 256 : 0);
+    // Fused to_qkv + attention (single-plane 16-bit modes, 64-wide heads, panels of whole items up to 144 rows): as many
+    // items per panel as keep panels x heads at a full round of the chip; small batches (fewer than half a round of
+    // workgroups) and the skinny window keep the separate kernels.
+    static const bool no_qa = getenv("DSN_NO_QKV_FUSE") != nullptr;
+    int qa_ipp = 0;
+    if (!no_qa && P == 1 && !fp8 && !skinny && D == H * 64 && S <= qkv_attention_max_rows()) {
+      int ipp = std::min(B, qkv_attention_max_rows() / S);
+      while (ipp > 1 && cdiv(B, ipp) * H < 256) --ipp;
+      if (cdiv(B, ipp) * H >= 128) qa_ipp = ipp;
+      const char* force = getenv("DSN_QA_IPP");  // tests: force the fused kernel with this many items per panel
+      if (force && atoi(force) >= 1 && atoi(force) * S <= qkv_attention_max_rows()) qa_ipp = atoi(force);
+    }
+    op16_t* AOp = qa_ipp ? wsbuf<op16_t>("dit_AOp", M * D) : nullptr;
     float* slabs = nullptr;
     int pend_n = 0;
     const float* pend_bias = nullptr;
@@ -1047,6 +1060,37 @@ struct dsn_ctx {
         launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, lnout, M * D, PL, (int)M, D, 1e-5f,
                              1, st, SA8);
       });
+      if (qa_ipp) {
+        // to_qkv + rotary + attention in one launch (qkv_attn.hip): panels of qa_ipp whole items x one head
+        QkvAttnDesc q;
+        memset(&q, 0, sizeof q);
+        q.A = Ap;
+        q.W = L.qkv.w;
+        q.bias = L.qkv.bias;
+        q.rope_cos = rc;
+        q.rope_sin = rs;
+        q.out = AOp;
+        q.M = (int)M;
+        q.D = D;
+        q.H = H;
+        q.S = S;
+        q.ipp = qa_ipp;
+        q.q_scale = 0.125f;
+        ProfRec pr;
+        if (profiling) {
+          HIPCHK(hipEventCreate(&pr.a));
+          HIPCHK(hipEventCreate(&pr.b));
+          pr.flops = 2.0 * (double)M * 3.0 * D * D + 4.0 * (double)B * H * (double)S * S * 64.0;
+          pr.tag = "dit.qkv_attention";
+          HIPCHK(hipEventRecord(pr.a, st));
+        }
+        const hipError_t e = qkv_attention_launch(q, PL, st);
+        if (profiling) {
+          HIPCHK(hipEventRecord(pr.b, st));
+          prof.push_back(pr);
+        }
+        if (e != hipSuccess) fail(DSN_EHIP, "qkv_attention launch failed: %s", hipGetErrorString(e));
+      } else {
       {  // q|k|v operand planes: rotary + 1/sqrt(dh) fused into the epilogue
         Tag tg(this, "dit.qkv");
         GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.qkv8, (int)M) : base_desc(Ap, M * D, L.qkv, 1, (int)M, (int)M);
@@ -1073,9 +1117,11 @@ struct dsn_ctx {
       }
       prof_launch("dit.attention", (double)M * D * 2.0 * P * 4.0, st,
                   [&] { launch_attention_mfma(QKVp, M * 3 * D, lnout, M * D, PL, B, S, H, 64, st, SA8); });
+      }
       {
         Tag tg(this, "dit.attn_out");
-        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.out8, (int)M) : base_desc(Ap, M * D, L.out, 1, (int)M, (int)M);
+        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.out8, (int)M)
+                         : base_desc(qa_ipp ? AOp : Ap, M * D, L.out, 1, (int)M, (int)M);
         if (fold_rows) {
           d.panel_rows = fold_rows;
           d.resid = X;

@@ -118,6 +118,23 @@ hipError_t igemm_skinny_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // the same with fp8 (MX) operands: d.a_scale / d.w_scale set, d.Cin = K/2 (byte pairs), K % 128 == 0
 hipError_t igemm_panel_fp8_launch(const GemmDesc& d, int bn, hipStream_t stream);
 
+// DiT to_qkv GEMM + rotary embedding + self-attention in one launch (qkv_attn.hip): row panels of `ipp` whole items
+// (ipp * S <= qkv_attention_max_rows()) x one 64-wide head per workgroup.  Single-plane 16-bit modes.
+struct QkvAttnDesc {
+  const op16_t* A;        // LayerNorm output operand plane [M][D]
+  const op16_t* W;        // to_qkv packed [3 D][D] K-major: q | k | v sections, head-major inside a section
+  const float* bias;      // [3 D] or null
+  const float* rope_cos;  // [S][32]
+  const float* rope_sin;
+  op16_t* out;            // attention output operand plane [M][D] (must not alias A)
+  int M, D, H, S;         // token rows (items x S), model width = 64 H, heads, tokens per item
+  int ipp;                // items per panel
+  int panels;             // set by the launcher
+  float q_scale;          // 1 / sqrt(64)
+};
+hipError_t qkv_attention_launch(const QkvAttnDesc& d, int pl, hipStream_t stream);
+int qkv_attention_max_rows();
+
 // Fused Oobleck ResidualUnit over 128-channel channels-last sequences (ru_fused.hip):
 //   out = X + conv1x1(act_mid(conv_k7_dil(A) + b7)) + b1 ;  planes(out) carry act_out for the consumer.
 // A / out_planes must not alias (neighbouring workgroups read each other's halo rows); X / out_f32 may.

@@ -150,6 +150,27 @@ def test_dit_c2_batch64_score_call_vs_oracle(dit_models):
     eng.close()
 
 
+@pytest.mark.parametrize("B,T,ipp,prec,tol", [(5, 8, 4, FP16, 4e-3), (7, 8, 16, FP16, 4e-3), (3, 40, 2, BF16, 3e-2),
+                                               (2, 100, 1, FP16, 4e-3), (9, 31, 4, FP16, 4e-3), (1, 143, 1, FP16, 4e-3)])
+def test_fused_qkv_attention_odd_shapes_vs_oracle(B, T, ipp, prec, tol, monkeypatch):
+    """qkv_attn.hip (to_qkv GEMM + rotary + attention in one launch) away from the benchmark shape, forced through
+    DSN_QA_IPP on a 2-head DiT (generic head mapping, K = 128 = two k-tiles): a last panel with fewer items, panels of
+    16 items of 9 tokens, 2 / 1 items of 41 / 101 / 144 tokens (3, 7 and 9 key tiles), bf16 operands; one score call
+    against the CPU oracle at the tolerance of the unfused tiny-DiT tests, bit-reproducible."""
+    monkeypatch.setenv("DSN_QA_IPP", str(ipp))
+    dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
+    dsd = odit.random_dit_weights(dcfg, 32, out_gain=0.005)
+    xt, t, mix = _score_inputs(B, T, 300 + B * T)
+    with torch.no_grad():
+        ref = odit.DiTScore(dsd, dcfg)(xt, t, mix)
+    eng = make_engine(dcfg, dsd, precision=prec)
+    out = eng.score(xt, t, mix)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < tol, rel_l2(out, ref)
+    assert torch.equal(eng.score(xt, t, mix), out)
+    eng.close()
+
+
 def test_dit_c2_batch64_chain_n30_vs_oracle(dit_models):
     """BASELINE C2 at its own batch: 64 mixtures, N = 30 + 1 corrector (60 score calls on the M = 2112 panel
     kernels, hipGraph replay) + decode of 128 sequences; items 0 / 31 / 63 against the CPU oracle under the
