@@ -35,3 +35,19 @@ def parameter_names(state_dict_keys: Iterable[str], scope: str = "") -> List[str
     """Names, in `parameters()` order, of the parameters among `state_dict_keys` under `scope`
     ("" = the whole LatentDiffSep module when `trainable_vae`, else "score_model.")."""
     return [k for k in state_dict_keys if k.startswith(scope) and not is_buffer(k)]
+
+
+def match_ema(shadow_params, state_dict, scope: str = ""):
+    """{name: EMA tensor} for a torch_ema `shadow_params` list against the checkpoint's own state_dict.
+    Matching is by position in `parameters()` order; it is checked by COUNT and by SHAPE of every pair, so a
+    buffer taken for a parameter (or the reverse) is an error naming the first mismatch instead of EMA weights
+    silently loaded under the wrong names."""
+    names = parameter_names(state_dict.keys(), scope)
+    if len(names) != len(shadow_params):
+        raise ValueError(f"EMA holds {len(shadow_params)} tensors but {len(names)} parameters are named under "
+                         f"'{scope or '<root>'}': buffer classification (checkpoint.is_buffer) does not fit this checkpoint")
+    for i, (name, t) in enumerate(zip(names, shadow_params)):
+        if tuple(t.shape) != tuple(state_dict[name].shape):
+            raise ValueError(f"EMA tensor {i} has shape {tuple(t.shape)} but parameter '{name}' is "
+                             f"{tuple(state_dict[name].shape)}: the EMA list does not line up with the parameter names")
+    return dict(zip(names, shadow_params))

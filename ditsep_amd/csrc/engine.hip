@@ -2521,6 +2521,11 @@ int dsn_bench_igemm(dsn_ctx* ctx, int B, int Lin, int Cin, int N, int taps, int 
       d.m_fast = (variant & 0x40) ? 1 : 0;
       if (variant & 0x20) {
         d.panel_rows = (variant >> 8) & 0xfff;
+        d.panel_wm = (variant & 0x80) ? 2 : 0;     // 8-wave variants; low bits then pick the ring (nst, BK 64 flag)
+        if (variant & 0x80) {
+          d.cfg_nst = variant & 0xf;
+          d.cfg_bk = (variant & 0x10) ? 64 : 32;
+        }
         hipError_t e2 = igemm_panel_launch(d, PL, (variant >> 20) & 0x3ff, nullptr);
         if (e2 != hipSuccess) fail(DSN_EHIP, "bench panel launch: %s", hipGetErrorString(e2));
         return;

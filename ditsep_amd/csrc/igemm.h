@@ -94,6 +94,7 @@ struct GemmDesc {
   const float* ln_colsum;
   float ln_eps;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
+  int panel_wm;    // row-panel kernel: wave rows (0 / 4: 4 x WN waves; 2: the 8-wave variants, 256-column tiles)
   int cfg_bm, cfg_bn, cfg_nst, cfg_bk;  // explicit tile configuration for igemm2_launch (0 = heuristic)
   int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)
   int m_fast;      // tile order inside an XCD's share: 1 = row panels fastest (few rows, many columns)

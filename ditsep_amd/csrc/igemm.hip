@@ -1038,15 +1038,16 @@ __global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kerne
 // masked.  Staging / ring / swizzle as in igemm2_kernel (BK = 32); row groups are dealt round-robin
 // to the waves, so the per-wave glds count (and its vmcnt) differs by one between waves.
 // ============================================================================
-template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0>
-__global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const GemmDesc d,
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0, int WM_ = 4>
+__global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_kernel(const GemmDesc d,
                                                                          const op16_t* __restrict__ zero_page) {
   // 4 wave rows x WN_ wave columns; the MT row sub-tiles of a panel are dealt MT/4 (+1 for the first MT%4 wave rows):
   // MT = 17: 5/4/4/4 = 272 rows (8 panels of 264 for M = 2112); MT = 9: 3/2/2/2 = 144 rows (16 panels of 132);
   // MT = 7: 2/2/2/1 = 112 rows.  Every wave owns 4 column sub-tiles (64 columns).
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows (TBN) | pad][TBK]
-  constexpr int NWAVES = 4 * WN_;
-  constexpr int MTW = (MT + 3) / 4;
+  // (WM_ = 2: 8 waves with taller wave tiles -- fewer fragment bytes read from LDS per MFMA, 256 registers per lane)
+  constexpr int NWAVES = WM_ * WN_;
+  constexpr int MTW = (MT + WM_ - 1) / WM_;
   constexpr int TBN = WN_ * 64;
   constexpr int AROWS = MT * 16;
   constexpr int ROWS = AROWS + TBN;
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(4 * WN_ * 64, 1) void igemm_panel_kernel(const Gemm
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave / WN_, wave_n = wave - wave_m * WN_;
-  constexpr int MBASE = MT / 4, MREM = MT % 4;
+  constexpr int MBASE = MT / WM_, MREM = MT % WM_;
   const int my_mt = MBASE + (wave_m < MREM ? 1 : 0);
   const int my_row0 = 16 * (wave_m * MBASE + min(wave_m, MREM));
   const int my_groups = (REM == 0 || wave < REM) ? GPW : GPW - 1;
@@ -1683,21 +1684,21 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
 }
 
 // Row-panel launcher: d.panel_rows rows per workgroup (<= 272), bn in {128, 256}.
-template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0>
+template <int P, int F16, int WN_, int NST, int TBK, int MT = 17, int EPI = 0, int WM_ = 4>
 static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI, WM_>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (MT * 16 + TBN) * TBK * sizeof(op16_t) + (d.ln_stats ? MT * 16 * 2 * sizeof(float) : 0);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI>), dim3(grid), dim3(4 * WN_ * 64), smem, stream, d,
-                     zp);
+  hipLaunchKernelGGL((igemm_panel_kernel<P, F16, WN_, NST, TBK, MT, EPI, WM_>), dim3(grid), dim3(WM_ * WN_ * 64), smem, stream,
+                     d, zp);
   return hipGetLastError();
 }
 
@@ -1771,6 +1772,7 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
   GemmDesc d = din;
   if (d.ksplit < 1) d.ksplit = 1;
   if (d.Cin % 64 != 0 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 || d.panel_rows > 17 * 16) return hipErrorInvalidValue;
+  if (d.panel_wm == 2 && d.cfg_bk == 32 && d.Cin % 32 != 0) return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 32 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
   if (d.img_w > 0) return hipErrorInvalidValue;
@@ -1784,6 +1786,16 @@ hipError_t igemm_panel_launch(const GemmDesc& din, int pl, int bn, hipStream_t s
     return f16 ? launch_panel_t<P_, 1, W_, NS_, BK_, MT_, E_>(d, zp, stream)                          \
                : launch_panel_t<P_, 0, W_, NS_, BK_, MT_, E_>(d, zp, stream);
 #define PCFGS(MT_, P_, W_, NS_, BK_) PCFGE(MT_, P_, W_, NS_, BK_, 0)
+  // 8-wave variants (d.panel_wm == 2): 2 wave rows x 4 wave columns, taller wave tiles; d.cfg_nst / d.cfg_bk pick the ring
+#define PCFG2(MT_, NS_, BK_, E_)                                                                                \
+  if (planes == 1 && bn == 256 && epi == E_ && d.panel_rows <= MT_ * 16 && (d.cfg_nst == 0 || d.cfg_nst == NS_) && \
+      (d.cfg_bk == 0 || d.cfg_bk == BK_))                                                                       \
+    return f16 ? launch_panel_t<1, 1, 4, NS_, BK_, MT_, E_, 2>(d, zp, stream)                                   \
+               : launch_panel_t<1, 0, 4, NS_, BK_, MT_, E_, 2>(d, zp, stream);
+  if (d.panel_wm == 2) {
+    PCFG2(9, 3, 64, 0) PCFG2(17, 2, 64, 0) PCFG2(17, 4, 32, 0) PCFG2(17, 2, 64, EPI_LNFOLD) PCFG2(17, 4, 32, EPI_LNFOLD)
+  }
+#undef PCFG2
   if (d.panel_rows <= 5 * 16) {  // 66-row panels x 128 columns: the N = D residual-stream GEMMs without split-K
     PCFGE(5, 1, 2, 4, 64, EPI_STATS) PCFGS(5, 1, 2, 4, 64)
   }

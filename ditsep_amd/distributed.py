@@ -47,6 +47,7 @@ class ShardPlan:
         if self.sizes[self.rank] != int(local_items):
             raise ValueError(f"rank {self.rank}: plan says {self.sizes[self.rank]} items, shard has {local_items}")
         self.n_src, self.length, self.device = int(n_src), int(length), device
+        self.send_device = torch.empty(0, device=device).device      # normalised ("cuda" -> cuda:<current>)
         self.max_items = max(self.sizes)
         self.even = min(self.sizes) == self.max_items
         shape = (self.max_items, self.n_src, self.length)
@@ -59,8 +60,15 @@ class ShardPlan:
         """The one data-path collective: every rank's [b_r, n, L] waveforms -> list of per-rank tensors on
         dst (views into the plan's receive buffers, valid until the next gather), None elsewhere."""
         b = self.sizes[self.rank]
-        if b and tuple(wav_local.shape) != (b, self.n_src, self.length):
-            raise ValueError(f"expected {(b, self.n_src, self.length)}, got {tuple(wav_local.shape)}")
+        if b:
+            # checked BEFORE the collective: a rank that raises after its peers entered dist.gather hangs them
+            if wav_local is None:
+                raise ValueError(f"rank {self.rank} owns {b} mixtures but passed no waveforms")
+            if tuple(wav_local.shape) != (b, self.n_src, self.length):
+                raise ValueError(f"expected {(b, self.n_src, self.length)}, got {tuple(wav_local.shape)}")
+            if wav_local.dtype != torch.float32 or wav_local.device != self.send_device:
+                raise ValueError(f"waveforms must be float32 on {self.send_device} (the plan's buffers), got "
+                                 f"{wav_local.dtype} on {wav_local.device}")
         if self.even:
             send = wav_local.contiguous()
         else:
@@ -71,6 +79,14 @@ class ShardPlan:
         if self.rank != self.dst:
             return None
         return [buf[:s] for buf, s in zip(self.recv, self.sizes)]
+
+
+_PLANS: dict = {}      # separate_sharded's plans when the caller passes none (cleared by reset_plans)
+
+
+def reset_plans():
+    """Forget the cached ShardPlans (call after destroying / re-creating the process group)."""
+    _PLANS.clear()
 
 
 def separate_sharded(separate_fn: Callable[[torch.Tensor], torch.Tensor], mix: torch.Tensor,
@@ -90,14 +106,21 @@ def separate_sharded(separate_fn: Callable[[torch.Tensor], torch.Tensor], mix: t
         shard = mix[s:e]
     wav = separate_fn(shard) if shard.shape[0] > 0 else None
     if plan is None:
-        # output geometry from whoever has items (an empty shard cannot know n, L)
-        meta = torch.zeros(2, dtype=torch.long, device=mix.device)
-        if wav is not None:
-            meta[0], meta[1] = wav.shape[1], wav.shape[2]
-        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
-        sizes = None if presharded else [b - a for a, b in (shard_bounds(mix.shape[0], world, r)
-                                                             for r in range(world))]
-        plan = ShardPlan(shard.shape[0], int(meta[0]), int(meta[1]), mix.device, group, dst, sizes=sizes)
+        # No plan passed: build one ONCE per (shard size, device, group, dst) and keep it -- the geometry exchange
+        # below (and ShardPlan's own size all_gather when presharded) are set-up collectives, not part of the data
+        # path; later calls with the same key issue the gather only.  The hot path (bench.py) passes its plan.
+        key = (shard.shape[0], mix.shape[0], bool(presharded), str(mix.device), id(group), dst)
+        plan = _PLANS.get(key)
+        if plan is None:
+            # output geometry from whoever has items (an empty shard cannot know n, L)
+            meta = torch.zeros(2, dtype=torch.long, device=mix.device)
+            if wav is not None:
+                meta[0], meta[1] = wav.shape[1], wav.shape[2]
+            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+            sizes = None if presharded else [b - a for a, b in (shard_bounds(mix.shape[0], world, r)
+                                                                 for r in range(world))]
+            plan = ShardPlan(shard.shape[0], int(meta[0]), int(meta[1]), mix.device, group, dst, sizes=sizes)
+            _PLANS[key] = plan
     parts = plan.gather(wav)
     if parts is None:
         return None

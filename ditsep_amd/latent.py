@@ -142,15 +142,8 @@ class LatentDiffSep:
         ema = ckpt.get("ema")
         if ema is not None:
             scope = "" if ckpt.get("trainable_vae", False) else "score_model."
-            names = checkpoint.parameter_names(raw.keys(), scope)
-            shadow = list(ema["shadow_params"])
-            if len(shadow) != len(names):
-                raise ValueError(f"EMA holds {len(shadow)} tensors but the state_dict has {len(names)} parameters "
-                                 f"under '{scope}*'")
-            for k, v in zip(names, shadow):
-                if tuple(v.shape) != tuple(raw[k].shape):
-                    raise ValueError(f"EMA tensor for {k}: shape {tuple(v.shape)} != {tuple(raw[k].shape)}")
-            self._ema_state = {**raw, **dict(zip(names, shadow))}
+            # by position in parameters() order, checked by count AND by the shape of every pair
+            self._ema_state = {**raw, **checkpoint.match_ema(list(ema["shadow_params"]), raw, scope)}
         if use_ema and self._ema_state is None:
             raise ValueError("use_ema=True but the checkpoint has no 'ema' entry")   # reference: _error_loading_ema
         self._using_ema = bool(use_ema)

@@ -1,27 +1,35 @@
-"""Name -> class registries with the reference's semantics
-(reference src/utils/registry.py:5-36: ValueError on an unknown name, a warning on re-registration)."""
+"""String-keyed class tables for predictors / correctors / SDEs.
+
+Interface contract taken from the reference (src/utils/registry.py:5-36): `register(name)` is a class decorator,
+`get_by_name` raises ValueError for a name nobody registered, registering a name twice replaces the class and warns,
+`get_all_names` lists the names.  The message texts are part of that contract (callers and tests match on them).
+"""
 import warnings
-from typing import Callable
 
 
 class Registry:
-    def __init__(self, managed_thing: str):
-        self.managed_thing = managed_thing
-        self._registry = {}
+    """One table; `kind` is the noun used in its messages ("Predictor", "Corrector", "SDE")."""
 
-    def register(self, name: str) -> Callable:
-        def inner(cls):
-            if name in self._registry:
-                warnings.warn(f"{self.managed_thing} with name '{name}' doubly registered, old class will be replaced.")
-            self._registry[name] = cls
-            return cls
+    __slots__ = ("managed_thing", "_table")
 
-        return inner
+    def __init__(self, kind: str):
+        self.managed_thing = kind
+        self._table = {}
+
+    def _add(self, name, cls):
+        if self._table.get(name) is not None:
+            warnings.warn(f"{self.managed_thing} with name '{name}' doubly registered, old class will be replaced.")
+        self._table[name] = cls
+        return cls
+
+    def register(self, name: str):
+        return lambda cls: self._add(name, cls)
 
     def get_by_name(self, name: str):
-        if name in self._registry:
-            return self._registry[name]
-        raise ValueError(f"{self.managed_thing} with name '{name}' unknown.")
+        try:
+            return self._table[name]
+        except KeyError:
+            raise ValueError(f"{self.managed_thing} with name '{name}' unknown.") from None
 
     def get_all_names(self):
-        return list(self._registry.keys())
+        return [*self._table]

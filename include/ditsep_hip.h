@@ -229,6 +229,10 @@ int dsn_profile_hbm(dsn_ctx* ctx, double* ms, double* bytes, int64_t* launches);
 int dsn_profile_rows(dsn_ctx* ctx, int max_rows, char* names, double* ms, double* flops, double* bytes,
                      int64_t* launches);
 
+/* ---- NOT PART OF THE ABI ------------------------------------------------------------------------------------
+ * dsn_test_igemm, dsn_debug_read and dsn_bench_igemm below are hooks for this repository's own tests, repro scripts and
+ * kernel sweeps.  They name internal workspace buffers and kernel variants, change without notice, and a binding of
+ * the reference-facing interface must not use them. */
 /* Test hook: run the implicit-GEMM kernel on caller-provided fp32 operands.
  * a [B][Lin][Cin] channels-last, w [N][taps*Cin]; out [B][rows_per_b][N] fp32 (no epilogue). */
 int dsn_test_igemm(dsn_ctx* ctx, const float* a, const float* w, float* out, int B, int Lin, int Cin, int N,

@@ -27,12 +27,17 @@ def _worker(rank, world, port, B, results):
     try:
         g = torch.Generator().manual_seed(0)
         mix = torch.randn((B, 1, 50), generator=g)
-        out = distributed.separate_sharded(_fake_separate, mix)
+        distributed.reset_plans()
+        ok = True
+        for rep in range(3):     # no plan passed: built on the first call, re-used afterwards (one gather per call)
+            out = distributed.separate_sharded(_fake_separate, mix)
+            assert len(distributed._PLANS) == 1
+            if rank == 0:
+                ok = ok and out is not None and torch.equal(out, _fake_separate(mix))
+            else:
+                assert out is None
         if rank == 0:
-            ok = out is not None and torch.equal(out, _fake_separate(mix))
             results.put(bool(ok))
-        else:
-            assert out is None
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +85,10 @@ def _bench_like_worker(rank, world, port, sizes, results):
         if b:
             with pytest.raises(ValueError):
                 plan.gather(torch.zeros((b, 2, 39)))
+            with pytest.raises(ValueError):          # no tensor / wrong dtype: refused before the collective too
+                plan.gather(None)
+            with pytest.raises(ValueError):
+                plan.gather(torch.zeros((b, 2, 40), dtype=torch.float64))
         results.put(bool(ok))
     finally:
         dist.destroy_process_group()
