@@ -430,6 +430,83 @@ __global__ __launch_bounds__(TPB) void residual_norm_kernel(float* __restrict__ 
   }
 }
 
+// Large-M form for D = 4 * TPB (the DiT's 1024): ONE ROW PER WORKGROUP, one quad per thread.  With a wave per row the
+// C2 shape (2112 rows) put 8 waves on a CU, each with five 16-byte loads in flight -- 40 KB per CU, well short of what
+// HBM needs to stay busy; here a CU holds ~33 waves and every load of a row is issued at once.  The row statistics go
+// through LDS in wave order (fixed order: bit-reproducible).
+template <int NS>
+__global__ __launch_bounds__(TPB) void residual_norm_row_kernel(float* __restrict__ x, const float* __restrict__ slabs,
+                                                                long slab_stride, const float* __restrict__ bias,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, op16_t* __restrict__ out,
+                                                                long ps, int planes, int D, float eps, int do_norm,
+                                                                unsigned char* __restrict__ o8s) {
+  __shared__ float red[2][TPB / 64];
+  const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+  const long rbase = (long)blockIdx.x * D;
+  f32x4 a = reinterpret_cast<const f32x4*>(x + rbase)[i];
+  f32x4 part[NS > 0 ? NS : 1];
+#pragma unroll
+  for (int z = 0; z < NS; ++z) part[z] = reinterpret_cast<const f32x4*>(slabs + z * slab_stride + rbase)[i];
+  f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  if (do_norm) {
+    g = reinterpret_cast<const f32x4*>(gamma)[i];
+    if (beta) be = reinterpret_cast<const f32x4*>(beta)[i];
+  }
+  if (NS > 0) {
+    if (bias) a += reinterpret_cast<const f32x4*>(bias)[i];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) a += part[z];
+    reinterpret_cast<f32x4*>(x + rbase)[i] = a;
+  }
+  f32x4 o = a;
+  if (do_norm) {
+    const float s = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) tot += red[0][w];
+    const float mean = tot / D;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dlt = a[r] - mean;
+      q += dlt * dlt;
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) qt += red[1][w];
+    const float rstd = rsqrtf(qt / D + eps);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (a[r] - mean) * rstd * g[r] + be[r];
+  }
+  if (o8s) {  // fp8 (MX) output: a 32-column scale block = the quads of 8 consecutive lanes
+    float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const int kx = dsn_mx_exp(amax);
+    reinterpret_cast<unsigned*>(out)[(rbase >> 2) + i] = dsn_fp8x4(o * dsn_pow2(-kx));
+    if ((lane & 7) == 0) o8s[(rbase >> 5) + (i >> 3)] = (unsigned char)(kx + 127);
+    return;
+  }
+  op16x4 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    op16_t h, l;
+    dsn_split(o[r], h, l, PL_F16(planes));
+    hi[r] = h;
+    lo[r] = l;
+  }
+  const long oi = (rbase >> 2) + i;
+  reinterpret_cast<op16x4*>(out)[oi] = hi;
+  if (PL_COUNT(planes) == 2) reinterpret_cast<op16x4*>(out + ps)[oi] = lo;
+}
+
 __global__ void timestep_features_kernel(const float* __restrict__ t, const float* __restrict__ w, int B, int half,
                                          op16_t* __restrict__ out, long ps, int planes) {
   const int n = B * half;
@@ -931,6 +1008,21 @@ void launch_residual_norm(float* x, const float* slabs, int nslab, long slab_str
     case 6: RN_LAUNCH(MV, 6, BT_); break;                                                  \
     case 7: RN_LAUNCH(MV, 7, BT_); break;                                                  \
     default: RN_LAUNCH(MV, 8, BT_); break;  /* pick_ksplit caps the split at 8 */          \
+  }
+  static const bool no_rowk = getenv("DSN_NO_LN_ROWK") != nullptr;
+  if (!no_rowk && D == 4 * TPB && rows > 256 && nslab <= 4) {  // bandwidth-bound: a row per workgroup, everything in flight
+#define RNR(NS_)                                                                                                     \
+  hipLaunchKernelGGL((residual_norm_row_kernel<NS_>), dim3(rows), dim3(TPB), 0, st, x, slabs, slab_stride, bias, gamma, \
+                     beta, out, ps, planes, D, eps, do_norm, o8s)
+    switch (nslab) {
+      case 0: RNR(0); break;
+      case 1: RNR(1); break;
+      case 2: RNR(2); break;
+      case 3: RNR(3); break;
+      default: RNR(4); break;
+    }
+#undef RNR
+    return;
   }
   if (D <= 1024 && rows <= 256) {  // latency-bound: whole-row load batches
     RN_SWITCH(4, true)
