@@ -691,11 +691,13 @@ __device__ __forceinline__ int swzk(int row) {
   return TBK == 32 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
 }
 
-template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0>
-__global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel(const GemmDesc d,
-                                                                                 const op16_t* __restrict__ zero_page) {
+// WTN: columns of a wave tile (64, or 32 for the 128 x 64 workgroup tile that gives a GEMM of few rows twice the workgroups)
+template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0, int WTN = 64>
+__global__ __launch_bounds__((TBM / 64) * (TBN / WTN) * 64, 1) void igemm2_kernel(const GemmDesc d,
+                                                                                  const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][plane][A rows | W rows][TBK]
-  constexpr int WN_ = TBN / 64;
+  constexpr int WN_ = TBN / WTN;
+  constexpr int NT = WTN / 16;
   constexpr int NWAVES = (TBM / 64) * WN_;
   constexpr int ROWS = TBM + TBN;             // staged rows per plane per k-tile (A rows then W rows)
   constexpr int PLANE_ELEMS = ROWS * TBK;
@@ -769,12 +771,12 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[NT][4];
   if constexpr ((LEAN & LEAN_SEEDED) != 0) {
-    seed_acc<4, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane);  // issued before any glds: lands first (in order)
+    seed_acc<NT, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * WTN, lane);  // issued before any glds: lands first (in order)
   } else {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -783,7 +785,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
   const int frow = lane & 15, fchunk = lane >> 4;
   const int fsw = swzk<TBK>(frow);
   const int a_row_off = (wm * 64 + frow) * TBK;
-  const int w_row_off = (TBM + wn * 64 + frow) * TBK;
+  const int w_row_off = (TBM + wn * WTN + frow) * TBK;
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -816,20 +818,21 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int coff = ((ks * 4 + fchunk) ^ fsw) * 8;
-      op16x8 fa[P][4], fw[P][4];
+      op16x8 fa[P][4], fw[P][NT];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k)
           fa[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + a_row_off + k * 16 * TBK + coff);
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
           fw[p][k] = *reinterpret_cast<const op16x8*>(base + p * PLANE_ELEMS + w_row_off + k * 16 * TBK + coff);
-        }
       }
 #if DSN_SETPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
+      for (int tn = 0; tn < NT; ++tn) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
           if (P == 2) {
@@ -844,7 +847,7 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / 64) * 64, 1) void igemm2_kernel
 #endif
     }
   }
-  epilogue_tile<P, F16, LEAN>(d, acc, m0 + wm * 64, n0 + wn * 64, lane, z);
+  epilogue_gen<P, F16, NT, 4, 0, LEAN>(d, acc, m0 + wm * 64, d.M, n0 + wn * WTN, lane, z);
 }
 
 // ============================================================================
@@ -1486,19 +1489,19 @@ const op16_t* zero_page() {
   return z;
 }
 
-template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0>
+template <int P, int F16, int TBM, int TBN, int NST, int TBK, int LEAN = 0, int WTN = 64>
 hipError_t launch_cfg(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = cdiv(d.M, TBM);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN, WTN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
   const size_t smem = (size_t)NST * P * (TBM + TBN) * TBK * sizeof(op16_t);
-  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN>), dim3(grid), dim3((TBM / 64) * (TBN / 64) * 64), smem,
-                     stream, d, zp);
+  hipLaunchKernelGGL((igemm2_kernel<P, F16, TBM, TBN, NST, TBK, LEAN, WTN>), dim3(grid), dim3((TBM / 64) * (TBN / WTN) * 64),
+                     smem, stream, d, zp);
   return hipGetLastError();
 }
 
@@ -1528,6 +1531,8 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
   if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)              \
     return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_>(d, zp, stream)                 \
                : launch_cfg<P_, 0, BM_, BN_, NS_, BK_>(d, zp, stream);
+  if (planes == 1 && bm == 128 && bn == 64 && nst == 3 && bk == 64)   // 4 waves of 64 x 32 (NCSN++ level 2)
+    return f16 ? launch_cfg<1, 1, 128, 64, 3, 64, 0, 32>(d, zp, stream) : launch_cfg<1, 0, 128, 64, 3, 64, 0, 32>(d, zp, stream);
   // split (2-plane) modes: 48 MFMAs per wave per 32-deep k-tile already amortise the barrier
   CFG(2, 128, 128, 2, 32) CFG(2, 256, 128, 2, 32) CFG(2, 128, 256, 2, 32) CFG(2, 256, 256, 2, 32)
   CFG(2, 256, 128, 3, 32)
@@ -1666,6 +1671,9 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
       if (k64 && d.N >= 256) { nst = 2; bk = 64; }
     } else if (k64) {                                    // (NCSN++ level 2: M = 8192)
       bk = 64;
+      // 128 x 128 tiles would leave half the chip idle (64 x 2 workgroups): 128 x 64 tiles of four 64 x 32 waves
+      static const bool no_n64 = getenv("DSN_NO_N64_TILE") != nullptr;
+      if (!no_n64 && d.ksplit <= 1 && tiles(128, 128) <= 160 && d.N % 64 == 0) bn = 64;
     }
   } else if (d.M >= 4096 && d.N >= 4096) {   // ConvTranspose phase GEMMs
     bm = bn = 256;
