@@ -386,14 +386,14 @@ def main():
     # runs over scripts/pmc_workload.py, gfx950 corrections by scripts/pmc_summary.py), taken at the commit
     # recorded in the file -- not re-measured by this run
     traffic, traffic_source = None, None
-    pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.precision}_{args.score}.json")
+    pmc_file = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.precision}_{args.score}.json")
     if os.path.exists(pmc_file) and B == 64 and dom is not None:
         pm = json.load(open(pmc_file))
         site = pm.get("sites", {}).get(dom["site"])
         if site:
             traffic = round(site["hbm_bytes_per_launch"])
             traffic_source = {"file": os.path.relpath(pmc_file, ROOT), "commit": pm.get("commit"),
-                              "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, replayed from the file",
+                              "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/pmc_workload.py (scripts/pmc_collect.sh), separate passes, gfx950 corrections by scripts/pmc_summary.py; replayed from the file (the bench itself under PMC exceeds the box's silence limit)",
                               "score_call_hbm_bytes": pm.get("score_call_hbm_bytes"),
                               "decode_hbm_bytes": pm.get("decode_hbm_bytes")}
     roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_MFMA_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None,

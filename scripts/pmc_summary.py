@@ -8,11 +8,11 @@ import collections, csv, glob, json, re, sys
 SETUP = ("pack_weight", "wn_scale", "snake_params", "packed_row_sum", "bias_plus_wbeta", "pack_bias", "randn", "fill", "copyBuffer",
          "distribution", "elementwise", "rope_tables")
 # bench.py call site -> substring of the rocprof kernel name at the C2 shape, headline (fp16) mode
-SITES = {"dit.ff_in": "igemm_panel_kernel<1, 1, 4, 2, 64, 17, 2>", "dit.ff_out": "igemm_panel_kernel<1, 1, 4, 3, 64, 9, 0>",
-         "dit.qkv": "igemm_panel_kernel<1, 1, 4, 3, 64, 7, 0>", "dit.attn_out": "igemm_panel_kernel<1, 1, 2, 4, 64, 5, 1>",
-         "dit.residual_norm": "residual_norm_kernel", "dit.attention": "attention_mfma_kernel",
-         "vae.residual_unit_fused": "ru_fused2_kernel"}
-
+SITES = {"dit.ff_in": "igemm_panel_kernel<1, 1, 4, 2, 64, 17, 2, 4>", "dit.ff_out": "igemm_panel_kernel<1, 1, 4, 3, 64, 9, 0, 4>",
+         "dit.qkv_attention": "qkv_attention_kernel<1, 3, 3>", "dit.attn_out": "igemm_panel_kernel<1, 1, 2, 4, 64, 5, 1, 4>",
+         "dit.residual_norm": "residual_norm_row_kernel<4>", "vae.residual_unit_fused": "ru_fused2_kernel"}
+NCSN_SITES = {"ncsnpp.conv3x3_level0": "igemm_halo3x3_kernel<1, 256, 4>", "ncsnpp.conv3x3_level1": "igemm_halo3x3_kernel<1, 128, 1>",
+              "ncsnpp.conv3x3_level2": "igemm2_kernel<1, 1, 128, 64, 3, 64, 0, 32>", "ncsnpp.gn_apply": "gn_apply_kernel"}
 
 def load(dirname, counter):
     per = collections.defaultdict(list)
@@ -44,11 +44,15 @@ def part(fetch_dir, write_dir, calls):
 score, score_total = part(sys.argv[1], sys.argv[2], 2)
 decode, decode_total = part(sys.argv[3], sys.argv[4], 1) if sys.argv[3] != "-" else ({}, None)
 sites = {}
-for site, pat in SITES.items():
+is_ncsn = any("halo3x3" in n for n in score)
+for site, pat in (NCSN_SITES if is_ncsn else SITES).items():
     for table in (score, decode):
         for name, r in table.items():
             if pat in name:
                 sites[site] = {"kernel": name, **r}
+    if site not in sites and not (site.startswith("vae.") and not decode):
+        # a tile configuration changed and the table above was not updated: fail instead of silently dropping the site
+        sys.exit(f"pmc_summary: no kernel matches call site {site} (pattern {pat!r}); kernels seen: {sorted(score)[:40]}")
 out = {"commit": sys.argv[6] if len(sys.argv) > 6 else None,
        "note": (sys.argv[7] + "; " if len(sys.argv) > 7 else "") +
                "batch 64, T=32, fp16 headline mode; hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md",
