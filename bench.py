@@ -529,6 +529,18 @@ def main():
                 if name == "fp8":
                     if not args.no_extra:
                         rec["c5_long_form"] = measure_c5(eng2, dcfg, dev)
+                        # BASELINE config 5 in its named precision: the same 30 s mixture, latent and injected noise
+                        # through the headline engine and through this one (N = 30, hipGraph-captured loop)
+                        L5 = 30 * FS
+                        mix5 = synthetic.synthetic_sources(1, dcfg.n_src, L5, FS, seed=4242).sum(1, keepdim=True).to(dev)
+                        y5 = eng.encode(mix5, seed=11)
+                        nz5 = torch.randn((1 + N_STEPS * (CORR + 1), 1, dcfg.n_src, 64, int(y5.shape[-1])), device=dev)
+                        w16 = eng.decode(eng.pc_sample(y5, nz5, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L5)
+                        w8 = eng2.decode(eng2.pc_sample(y5, nz5, N=N_STEPS, corrector_steps=CORR, snr=SNR, t_eps=T_EPS)[0], L5)
+                        rec["c5_long_form"]["rel_l2_waveform_vs_headline_mode"] = float(
+                            (w8.double() - w16.double()).norm() / w16.double().norm())
+                        rec["c5_long_form"]["parity_note"] = ("vs the fp32 CPU oracle (T = 235, N = 3): "
+                                                              "tests/test_gpu_headline.py::test_dit_c5_fp8_long_form_chain_parity_figure")
                     eng2.profile_begin()
                     step(20_000, eng2)
                     p2 = eng2.profile_end()

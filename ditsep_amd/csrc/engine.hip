@@ -520,6 +520,9 @@ struct dsn_ctx {
         L.be2 = maybe(lp + "ff_norm.beta");
         if (fp8) {
           L.qkv8 = pack_linear_fp8(lp + "self_attn.to_qkv.weight", "", false, st);
+          // (also in 16 bits: where the fused to_qkv + attention kernel applies, that block runs on fp16 operands and
+          // hands its output to the fp8 out-projection as e4m3 + scales)
+          L.qkv = pack_linear(lp + "self_attn.to_qkv.weight", "", false, st);
           L.out8 = pack_linear_fp8(lp + "self_attn.to_out.weight", "", false, st);
           L.ff1_8 = pack_linear_fp8(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
           L.ff2_8 = pack_linear_fp8(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
@@ -1040,7 +1043,7 @@ struct dsn_ctx {
     // workgroups) and the skinny window keep the separate kernels.
     static const bool no_qa = getenv("DSN_NO_QKV_FUSE") != nullptr;
     int qa_ipp = 0;
-    if (!no_qa && P == 1 && !fp8 && !skinny && D == H * 64 && S <= qkv_attention_max_rows()) {
+    if (!no_qa && P == 1 && !skinny && D == H * 64 && S <= qkv_attention_max_rows()) {
       int ipp = std::min(B, qkv_attention_max_rows() / S);
       while (ipp > 1 && cdiv(B, ipp) * H < 256) --ipp;
       if (cdiv(B, ipp) * H >= 128) qa_ipp = ipp;
@@ -1057,8 +1060,9 @@ struct dsn_ctx {
       // algorithmic bytes of the fused reduce + LayerNorm: x in/out (when slabs are pending), slabs in, planes out
       auto ln_bytes = [&](int np) { return (double)M * D * (4.0 * (np ? 2 : 1) + 4.0 * np + 2.0 * P); };
       prof_launch("dit.residual_norm", ln_bytes(pend_n), st, [&] {
-        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, lnout, M * D, PL, (int)M, D, 1e-5f,
-                             1, st, SA8);
+        // (fused to_qkv + attention reads 16-bit planes, in the fp8 mode too)
+        launch_residual_norm(X, slabs, pend_n, slab_stride, pend_bias, L.g1, L.be1, qa_ipp ? Ap : lnout, M * D, PL,
+                             (int)M, D, 1e-5f, 1, st, qa_ipp ? nullptr : SA8);
       });
       if (qa_ipp) {
         // to_qkv + rotary + attention in one launch (qkv_attn.hip): panels of qa_ipp whole items x one head
@@ -1069,7 +1073,9 @@ struct dsn_ctx {
         q.bias = L.qkv.bias;
         q.rope_cos = rc;
         q.rope_sin = rs;
-        q.out = AOp;
+        q.out = fp8 ? nullptr : AOp;
+        q.out8 = fp8 ? A8 : nullptr;       // fp8 mode: e4m3 + E8M0 scales for the fp8 out-projection
+        q.out8_scale = fp8 ? SA8 : nullptr;
         q.M = (int)M;
         q.D = D;
         q.H = H;

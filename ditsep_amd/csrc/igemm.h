@@ -127,7 +127,9 @@ struct QkvAttnDesc {
   const float* bias;      // [3 D] or null
   const float* rope_cos;  // [S][32]
   const float* rope_sin;
-  op16_t* out;            // attention output operand plane [M][D] (must not alias A)
+  op16_t* out;            // attention output operand plane [M][D] (must not alias A), or null with out8
+  unsigned char* out8;    // fp8 (MX) output instead: e4m3 bytes [M][D] + E8M0 block scales [M][D/32] (fp8 out-projection)
+  unsigned char* out8_scale;
   int M, D, H, S;         // token rows (items x S), model width = 64 H, heads, tokens per item
   int ipp;                // items per panel
   int panels;             // set by the launcher

@@ -281,9 +281,34 @@ __global__ __launch_bounds__(512, 1) void qkv_attention_kernel(const QkvAttnDesc
       }
     }
     // query qt*16 + r16, features dt*16 + 4 g4 + r of this head -> the out-projection's operand plane
-    if (qt * 16 + r16 < S) {
-      const float inv = 1.f / lsum;
-      op16_t* o = d.out + (long)(m0 + base + qt * 16 + r16) * d.D + head * 64 + 4 * g4;
+    const float inv = 1.f / lsum;
+    const long orow = (long)(m0 + base + qt * 16 + r16);
+    if (d.out8) {
+      // fp8 (MX) output for the fp8 out-projection: a 32-feature scale block = a pair of feature tiles across the 4 lane
+      // groups that share the query (attention.hip::store_query_out); the shuffles run for every lane, stores are masked
+#pragma unroll
+      for (int dp = 0; dp < 2; ++dp) {
+        f32x4 v[2];
+        float amax = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          v[u] = oacc[2 * dp + u] * inv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(v[u][r]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int k = dsn_mx_exp(amax);
+        const float sc = dsn_pow2(-k);
+        if (qt * 16 + r16 < S) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            *reinterpret_cast<unsigned*>(d.out8 + orow * d.D + head * 64 + (2 * dp + u) * 16 + 4 * g4) = dsn_fp8x4(v[u] * sc);
+          if (g4 == 0) d.out8_scale[orow * (d.D >> 5) + ((head * 64 + dp * 32) >> 5)] = (unsigned char)(k + 127);
+        }
+      }
+    } else if (qt * 16 + r16 < S) {
+      op16_t* o = d.out + orow * d.D + head * 64 + 4 * g4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         op16x4 h;
@@ -323,7 +348,8 @@ int qkv_attention_max_rows() { return QA_TM; }
 hipError_t qkv_attention_launch(const QkvAttnDesc& din, int pl, hipStream_t stream) {
   QkvAttnDesc d = din;
   if (PL_COUNT(pl) != 1 || d.D != d.H * 64 || d.D % QA_BK != 0 || d.S < 1 || d.ipp < 1 || d.ipp * d.S > QA_TM ||
-      d.M <= 0 || d.M % d.S != 0 || !d.A || !d.W || !d.out || !d.rope_cos || !d.rope_sin || d.A == d.out)
+      d.M <= 0 || d.M % d.S != 0 || !d.A || !d.W || (!d.out && !d.out8) || (d.out8 && !d.out8_scale) || !d.rope_cos ||
+      !d.rope_sin || d.A == d.out)
     return hipErrorInvalidValue;
   d.panels = cdiv(d.M / d.S, d.ipp);
   const op16_t* zp = qa_zero_page();
