@@ -23,6 +23,9 @@ pytestmark = pytest.mark.gpu
 X3, BF16, FP16, FP16X3 = 2, 1, 3, 4
 # per-GEMM relative-L2 bounds: operand rounding 2^-9 (bf16), 2^-12 (fp16), ~2^-17 / 2^-22 (split)
 TOL = {X3: 2e-5, BF16: 1.5e-2, FP16: 1.5e-3, FP16X3: 2e-6}
+# (single-GEMM tolerances per operand format.  Tiny-network tests below use 4e-3 ... 5e-3 in fp16: narrow random layers are
+# not contractive, so one operand rounding is amplified -- see the note at the top of tests/test_gpu_configs.py; the
+# north-star 1e-3 bound is asserted on the full-size BASELINE chains.)
 
 
 @pytest.fixture(scope="module")
