@@ -767,6 +767,13 @@ struct dsn_ctx {
       audit_span("gn_stats", d.gn_stats, 0, nb * (d.rows_per_b / 64) * (long)(d.N / 4) * 2 * e32, d);
       if (nb * (d.rows_per_b / 64) * (long)(d.N / 4) * 2 > ncs_slot_floats)
         fail(DSN_EINVAL, "audit: GroupNorm partials overflow their statistics slot");
+      if (d.gn_stats2) {
+        if (d.gn_qoff2 < 0 || d.gn_qoff2 + d.N / 4 > d.gn_nq2 ||
+            nb * (d.rows_per_b / 64) * (long)d.gn_nq2 * 2 > ncs_slot_floats)
+          fail(DSN_EINVAL, "audit: concat GroupNorm partials outside their slot (nq2=%d qoff2=%d N=%d)", d.gn_nq2,
+               d.gn_qoff2, d.N);
+        audit_span("gn_stats2", d.gn_stats2, 0, nb * (d.rows_per_b / 64) * (long)d.gn_nq2 * 2 * e32, d);
+      }
     }
     if (d.ln_stats) {
       audit_span("ln_stats", d.ln_stats, 0, (long)d.M * d.ln_np * 2 * e32, d);
@@ -809,6 +816,7 @@ struct dsn_ctx {
       g.out_f32 = slabs;
       g.out_planes = nullptr;
       g.gn_stats = nullptr;
+      g.gn_stats2 = nullptr;
       g.cfg_bm = 128;
       g.cfg_bn = 128;
       g.cfg_nst = 3;

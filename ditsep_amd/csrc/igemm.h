@@ -43,7 +43,11 @@ struct GemmDesc {
   // consumer (gn_apply) combines the slices x quads of a group in a fixed order (Chan's parallel formula):
   // bit-reproducible, no E[x^2] - E[x]^2 cancellation.  Needs rows_per_b % 64 == 0, N % 4 == 0.  null = off
   float* gn_stats;
-  int gn_G, gn_cpg;
+  // the same partials a second time, in the layout of a CONCAT buffer this output is a channel slice of
+  // ([B][S][gn_nq2][2], this tensor's quads starting at gn_qoff2): the GroupNorm over the concatenation then needs no
+  // statistics pass of its own.  null = off
+  float* gn_stats2;
+  int gn_nq2, gn_qoff2;
   float* out_f32;      // or null
   // (out_scale sits in the 8-byte-aligned half of its slot on purpose: with f32_op first, kernels that compile f32_op out
   // fetched the kernarg chunk [out_scale | out_planes | ...] as one 16-byte load starting at an odd dword, could not

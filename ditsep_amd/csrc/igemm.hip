@@ -454,8 +454,12 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
       DSN_GN_MERGE(8) DSN_GN_MERGE(4) DSN_GN_MERGE(2) DSN_GN_MERGE(1)
 #undef DSN_GN_MERGE
       const int n = nw0 + tn * 16 + nq;
-      if ((lane & 15) == 0 && n < d.N)
+      if ((lane & 15) == 0 && n < d.N) {
         *reinterpret_cast<float2*>(d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2) = float2{mean, m2};
+        if (d.gn_stats2)
+          *reinterpret_cast<float2*>(d.gn_stats2 + ((((long)b * S + slice) * d.gn_nq2) + d.gn_qoff2 + (n >> 2)) * 2) =
+              float2{mean, m2};
+      }
     }
   }
 }
