@@ -988,6 +988,8 @@ struct dsn_ctx {
     const char* skx = getenv("DSN_SKINNY_MAX");
     const int skinny_min = skm ? atoi(skm) : 1, skinny_max = skx ? std::min(atoi(skx), 128) : 80;
     const bool skinny = !no_skinny && P == 1 && !fp8 && M >= skinny_min && M <= skinny_max && D % 256 == 0;
+    const char* sks = getenv("DSN_SKINNY_KS");  // development: split-K of the skinny N = D GEMMs (default 8)
+    const int skinny_ks = sks ? std::max(1, std::min(atoi(sks), 8)) : 8;
     int fold_rows = 0;
     if (fold_ln && use_panel_ok(D) && !skinny) {
       for (int rounds = 1; rounds <= 4 && !fold_rows; ++rounds) {
@@ -1154,7 +1156,7 @@ struct dsn_ctx {
         static const char* ocfg = getenv("DSN_OUT_CFG");  // "bn,ksplit" (development)
         int obn = 128, oks = 2;
         if (ocfg) sscanf(ocfg, "%d,%d", &obn, &oks);
-        d.ksplit = skinny ? 8 : ((short_panel || fp8) ? oks : pick_ksplit(d));
+        d.ksplit = skinny ? skinny_ks : ((short_panel || fp8) ? oks : pick_ksplit(d));
         if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, obn) * oks, (fp8 && obn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
@@ -1221,7 +1223,7 @@ struct dsn_ctx {
         static const char* fcfg = getenv("DSN_FF2_CFG");
         int fbn = 256, fks = 4;
         if (fcfg) sscanf(fcfg, "%d,%d", &fbn, &fks);
-        d.ksplit = skinny ? 8 : ((short_panel || fp8) ? fks : pick_ksplit(d));
+        d.ksplit = skinny ? skinny_ks : ((short_panel || fp8) ? fks : pick_ksplit(d));
         if (short_panel || fp8) d.panel_rows = panel_rows_for(cdiv(D, fbn) * fks, (fp8 && fbn == 256) ? 208 : 272);
         if (d.ksplit > 1) {
           slabs = wsbuf<float>("dit_slabs", slab_stride * 8);
