@@ -150,6 +150,30 @@ def test_dit_c2_batch64_score_call_vs_oracle(dit_models):
     eng.close()
 
 
+def test_dit_c4_three_speakers_batch64_score_call_vs_oracle():
+    """BASELINE config 4's score network (3 sources: io 192 + 64 concat channels) at the benchmark batch: one score
+    call over 64 mixtures on the panel / fused-attention kernels against the CPU oracle (the N = 30 three-speaker
+    chain with PIT runs at B = 2 in test_gpu_configs.py)."""
+    from ditsep_amd import synthetic
+    torch.set_num_threads(16)
+    dcfg = synthetic.DiTConfig(n_src=3)
+    dsd = synthetic.random_dit_weights(dcfg, 5, out_gain=0.002, skip_gain=0.02)
+    g = torch.Generator().manual_seed(75)
+    xt = 3.0 * torch.randn((B64, 3, 64, T32), generator=g)
+    mix = torch.randn((B64, 1, 64, T32), generator=g)
+    t = torch.linspace(0.97, 0.03, B64)
+    with torch.no_grad():
+        ref = odit.DiTScore(dsd, dcfg)(xt, t, mix)
+    eng = make_engine(dcfg, dsd, precision=FP16)
+    out = eng.score(xt, t, mix)
+    e = rel_l2(out, ref)
+    worst = max(rel_l2(out[b], ref[b]) for b in range(B64))
+    _log(f"dit (3 speakers) score call fp16 B=64: rel-L2 {e:.3e}, worst item {worst:.3e}")
+    assert e < SCORE_CALL_TOL and worst < 2 * SCORE_CALL_TOL, (e, worst)
+    assert torch.equal(eng.score(xt, t, mix), out)
+    eng.close()
+
+
 @pytest.mark.parametrize("B,T,ipp,prec,tol", [(5, 8, 4, FP16, 4e-3), (7, 8, 16, FP16, 4e-3), (3, 40, 2, BF16, 3e-2),
                                                (2, 100, 1, FP16, 4e-3), (9, 31, 4, FP16, 4e-3), (1, 143, 1, FP16, 4e-3)])
 def test_fused_qkv_attention_odd_shapes_vs_oracle(B, T, ipp, prec, tol, monkeypatch):
