@@ -1048,13 +1048,13 @@ struct dsn_ctx {
     };
     static const char* qkv_panel_env = getenv("DSN_QKV_PANEL");
     const int qkv_panel = (use_panel && qkv_panel_env) ? atoi(qkv_panel_env) : (short_panel ? 256 : 0);
-    // Fused to_qkv + attention (single-plane 16-bit modes, 64-wide heads, panels of whole items up to 144 rows): as many
-    // items per panel as keep panels x heads at a full round of the chip; small batches (fewer than half a round of
-    // workgroups) and the skinny window keep the separate kernels.
+    // Fused to_qkv + attention (single-plane 16-bit modes, 64-wide heads, panels of whole items up to 144 rows -- 240 for
+    // one long item, the 2-stage-ring variant): as many items per panel as keep panels x heads at a full round of the
+    // chip; small batches (fewer than half a round of workgroups) and the skinny window keep the separate kernels.
     static const bool no_qa = getenv("DSN_NO_QKV_FUSE") != nullptr;
     int qa_ipp = 0;
     if (!no_qa && P == 1 && !skinny && D == H * 64 && S <= qkv_attention_max_rows()) {
-      int ipp = std::min(B, qkv_attention_max_rows() / S);
+      int ipp = std::min(B, std::max(1, 144 / S));  // several items share a panel only in the 144-row tile
       while (ipp > 1 && cdiv(B, ipp) * H < 256) --ipp;
       if (cdiv(B, ipp) * H >= 128) qa_ipp = ipp;
       const char* force = getenv("DSN_QA_IPP");  // tests: force the fused kernel with this many items per panel

@@ -140,7 +140,8 @@ struct QkvAttnDesc {
   float q_scale;          // 1 / sqrt(64)
 };
 hipError_t qkv_attention_launch(const QkvAttnDesc& d, int pl, hipStream_t stream);
-int qkv_attention_max_rows();
+int qkv_attention_max_rows();            // tallest panel (240)
+int qkv_attention_panel_rows(int rows);   // tile height the launcher picks for panels of `rows` rows (144 | 240)
 
 // Fused Oobleck ResidualUnit over 128-channel channels-last sequences (ru_fused.hip):
 //   out = X + conv1x1(act_mid(conv_k7_dil(A) + b7)) + b1 ;  planes(out) carry act_out for the consumer.

@@ -19,26 +19,32 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-constexpr int QA_TM = 144, QA_TN = 192, QA_BK = 64;
-constexpr int QA_ROWS = QA_TM + QA_TN;          // staged rows per k-tile: A rows then W rows
-constexpr int QA_STAGE = QA_ROWS * QA_BK;       // elements per ring stage
-constexpr int QA_GPW = 6;                       // glds wave-instructions (8 rows x 128 B) per wave per k-tile
-constexpr int QA_AG = QA_TM / 8, QA_WG = QA_TN / 8;  // 18 + 24 live groups, 6 dummy ones keep the count uniform
+constexpr int QA_TN = 192, QA_BK = 64;
+constexpr int QA_TM_MAX = 240;                  // tallest panel instantiated (long-form: one 236-token item)
 
 // chunk swizzle of a 128-byte LDS row (see igemm.hip::swzk<64>): conflict-free ds_read_b128 of MFMA fragments
 __device__ __forceinline__ int qa_swz(int row) { return (row >> 1) & 7; }
 // element offset of (row, column c) inside one [rows][64] operand image
 __device__ __forceinline__ int qa_off(int row, int c) { return row * 64 + ((((c >> 3) ^ qa_swz(row))) << 3) + (c & 7); }
 
-template <int F16, int NST, int NKT>
+// QA_TM: panel rows of the tile -- 144 (9 row sub-tiles as 5 + 4, 3-stage ring) for the 4 s shapes, 240 (15 as 8 + 7,
+// 2-stage ring: 111 KB) for one long-form item of up to 240 tokens (BASELINE config 5: 236)
+template <int F16, int NST, int NKT, int QA_TM = 144>
 __global__ __launch_bounds__(512, 1) void qkv_attention_kernel(const QkvAttnDesc d, const op16_t* __restrict__ zero_page) {
-  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][336][64] ring | dummy [8][64]
+  extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][QA_TM + 192][64] ring | dummy [8][64]
+  constexpr int QA_ROWS = QA_TM + QA_TN;          // staged rows per k-tile: A rows then W rows
+  constexpr int QA_STAGE = QA_ROWS * QA_BK;       // elements per ring stage
+  constexpr int QA_AG = QA_TM / 8, QA_WG = QA_TN / 8;  // live row groups (8 rows x 128 B each)
+  constexpr int QA_GPW = (QA_AG + QA_WG + 7) / 8;      // glds wave-instructions per wave per k-tile (dummies fill up)
+  constexpr int MT = QA_TM / 16;                       // row sub-tiles: wave row 0 takes MT0, wave row 1 the rest
+  constexpr int MT0 = (MT + 1) / 2, MTW = MT0;
+  static_assert(3 * QA_TM * 64 <= NST * QA_STAGE, "the q | k | v images must fit in the ring");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int mtw = wm == 0 ? 5 : 4;       // row sub-tiles of this wave
-  const int row0 = wm == 0 ? 0 : 80;     // first row of this wave inside the panel
+  const int mtw = wm == 0 ? MT0 : MT - MT0;   // row sub-tiles of this wave
+  const int row0 = wm == 0 ? 0 : MT0 * 16;    // first row of this wave inside the panel
 
   // XCD-aware bijective remap; tiles ordered (head group of 4, panel, head in group): an XCD's contiguous share is a few
   // heads x a few panels, so both its weight columns and its activation panels stay in its L2
@@ -97,11 +103,11 @@ __global__ __launch_bounds__(512, 1) void qkv_attention_kernel(const QkvAttnDesc
     }
   };
 
-  f32x4 acc[3][5];
+  f32x4 acc[3][MTW];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int r16 = lane & 15, g4 = lane >> 4;
   const int fsw = qa_swz(r16);
@@ -129,14 +135,14 @@ __global__ __launch_bounds__(512, 1) void qkv_attention_kernel(const QkvAttnDesc
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + g4) ^ fsw) << 3;
-      op16x8 fa[5], fw[3];
+      op16x8 fa[MTW], fw[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) fw[k] = *reinterpret_cast<const op16x8*>(base + w_row_off + k * 16 * QA_BK + coff);
 #pragma unroll
-      for (int k = 0; k < 5; ++k)
+      for (int k = 0; k < MTW; ++k)
         if (k < mtw) fa[k] = *reinterpret_cast<const op16x8*>(base + a_row_off + k * 16 * QA_BK + coff);
 #pragma unroll
-      for (int tm = 0; tm < 5; ++tm)
+      for (int tm = 0; tm < MTW; ++tm)
         if (tm < mtw) {
 #pragma unroll
           for (int tn = 0; tn < 3; ++tn) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void qkv_attention_kernel(const QkvAttnDesc
   const int rope_first = wn == 0 ? 0 : (wn == 1 ? 1 : -1);
   const int nq = g4 * 4;
 #pragma unroll
-  for (int tm = 0; tm < 5; ++tm) {
+  for (int tm = 0; tm < MTW; ++tm) {
     if (tm >= mtw) continue;
     const int row = row0 + tm * 16 + r16;          // row inside the panel
     if (d.bias) {
@@ -330,24 +336,25 @@ const op16_t* qa_zero_page() {
   return z;
 }
 
-template <int F16, int NST, int NKT>
+template <int F16, int NST, int NKT, int TM>
 hipError_t qa_launch_t(const QkvAttnDesc& d, const op16_t* zp, hipStream_t stream) {
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<F16, NST, NKT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attention_kernel<F16, NST, NKT, TM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const size_t smem = (size_t)(NST * QA_STAGE + 8 * QA_BK) * sizeof(op16_t);
-  hipLaunchKernelGGL((qkv_attention_kernel<F16, NST, NKT>), dim3(d.panels * d.H), dim3(512), smem, stream, d, zp);
+  const size_t smem = (size_t)(NST * (TM + QA_TN) * QA_BK + 8 * QA_BK) * sizeof(op16_t);
+  hipLaunchKernelGGL((qkv_attention_kernel<F16, NST, NKT, TM>), dim3(d.panels * d.H), dim3(512), smem, stream, d, zp);
   return hipGetLastError();
 }
 
 }  // namespace
 
-int qkv_attention_max_rows() { return QA_TM; }
+int qkv_attention_max_rows() { return QA_TM_MAX; }
+int qkv_attention_panel_rows(int rows) { return rows <= 144 ? 144 : QA_TM_MAX; }
 
 hipError_t qkv_attention_launch(const QkvAttnDesc& din, int pl, hipStream_t stream) {
   QkvAttnDesc d = din;
-  if (PL_COUNT(pl) != 1 || d.D != d.H * 64 || d.D % QA_BK != 0 || d.S < 1 || d.ipp < 1 || d.ipp * d.S > QA_TM ||
+  if (PL_COUNT(pl) != 1 || d.D != d.H * 64 || d.D % QA_BK != 0 || d.S < 1 || d.ipp < 1 || d.ipp * d.S > QA_TM_MAX ||
       d.M <= 0 || d.M % d.S != 0 || !d.A || !d.W || (!d.out && !d.out8) || (d.out8 && !d.out8_scale) || !d.rope_cos ||
       !d.rope_sin || d.A == d.out)
     return hipErrorInvalidValue;
@@ -356,10 +363,15 @@ hipError_t qkv_attention_launch(const QkvAttnDesc& din, int pl, hipStream_t stre
   if (!zp) return hipErrorOutOfMemory;
   const int nqt = (d.S + 15) / 16;
   const int f16 = PL_F16(pl);
-#define QA(NKT_)                                                        \
-  return f16 ? qa_launch_t<1, 3, NKT_>(d, zp, stream) : qa_launch_t<0, 3, NKT_>(d, zp, stream);
-  if (nqt <= 3) { QA(3) }
-  if (nqt <= 5) { QA(5) }
-  QA(9)
+#define QA(NST_, NKT_, TM_) \
+  return f16 ? qa_launch_t<1, NST_, NKT_, TM_>(d, zp, stream) : qa_launch_t<0, NST_, NKT_, TM_>(d, zp, stream);
+  if (d.ipp * d.S <= 144) {
+    if (nqt <= 3) { QA(3, 3, 144) }
+    if (nqt <= 5) { QA(3, 5, 144) }
+    QA(3, 9, 144)
+  }
+  // tall panels (up to 240 rows, e.g. one 30 s item of 236 tokens): 2-stage ring
+  if (nqt <= 9) { QA(2, 9, 240) }
+  QA(2, 15, 240)
 #undef QA
 }

@@ -175,11 +175,13 @@ def test_dit_c4_three_speakers_batch64_score_call_vs_oracle():
 
 
 @pytest.mark.parametrize("B,T,ipp,prec,tol", [(5, 8, 4, FP16, 4e-3), (7, 8, 16, FP16, 4e-3), (3, 40, 2, BF16, 3e-2),
-                                               (2, 100, 1, FP16, 4e-3), (9, 31, 4, FP16, 4e-3), (1, 143, 1, FP16, 4e-3)])
+                                               (2, 100, 1, FP16, 4e-3), (9, 31, 4, FP16, 4e-3), (1, 143, 1, FP16, 4e-3),
+                                               (2, 235, 1, FP16, 4e-3), (3, 144, 1, BF16, 3e-2), (1, 239, 1, FP16, 4e-3)])
 def test_fused_qkv_attention_odd_shapes_vs_oracle(B, T, ipp, prec, tol, monkeypatch):
     """qkv_attn.hip (to_qkv GEMM + rotary + attention in one launch) away from the benchmark shape, forced through
     DSN_QA_IPP on a 2-head DiT (generic head mapping, K = 128 = two k-tiles): a last panel with fewer items, panels of
-    16 items of 9 tokens, 2 / 1 items of 41 / 101 / 144 tokens (3, 7 and 9 key tiles), bf16 operands; one score call
+    16 items of 9 tokens, 2 / 1 items of 41 / 101 / 144 tokens (3, 7 and 9 key tiles), bf16 operands, and the tall
+    240-row tile (2-stage ring) at 236 (BASELINE config 5), 145 and 240 tokens; one score call
     against the CPU oracle at the tolerance of the unfused tiny-DiT tests, bit-reproducible."""
     monkeypatch.setenv("DSN_QA_IPP", str(ipp))
     dcfg = odit.DiTConfig(n_src=2, embed_dim=128, depth=2, num_heads=2)
