@@ -80,6 +80,8 @@ struct DitLayer {
   // ff_norm folded into FF-in (single-plane modes): W * diag(gamma) packed, its rounded row sums, bias + W beta
   Packed ff1f;
   float* ff1_colsum = nullptr;
+  Packed8 ff1f8;  // fp8 mode: the same fold on the MX-quantised W * diag(gamma), row sums of the dequantised bytes
+  float* ff1_colsum8 = nullptr;
 };
 
 struct ResUnit {
@@ -124,6 +126,7 @@ struct dsn_ctx {
   int P = 2;   // operand planes
   int PL = 2;  // DSN_PL(P, fp16 flag) as the kernels take it
   bool fp8 = false;  // DSN_PREC_FP8: DiT layer GEMMs on fp8 (MX) operands, the rest single-plane fp16
+  bool fold_ln8 = false;  // the same in the fp8 mode (raw x' as e4m3 + block scales)
   bool fold_ln = false;  // ff_norm folded into FF-in, to_out without split-K writing the residual stream itself
   bool finalized = false;
   bool use_graphs = false;
@@ -500,6 +503,7 @@ struct dsn_ctx {
     }
     const int D = cfg.dit_embed_dim;
     fold_ln = P == 1 && !fp8 && D % 64 == 0 && getenv("DSN_NO_LN_FOLD") == nullptr;
+    fold_ln8 = fp8 && D % 128 == 0 && getenv("DSN_NO_LN_FOLD") == nullptr;
     if (cfg.score_kind == DSN_SCORE_DIT) {
       const std::string sp = "score_model.";
       if (D % 64 != 0 || cfg.dit_heads <= 0 || D / cfg.dit_heads != 64 || D % cfg.dit_heads != 0)
@@ -526,6 +530,26 @@ struct dsn_ctx {
           L.out8 = pack_linear_fp8(lp + "self_attn.to_out.weight", "", false, st);
           L.ff1_8 = pack_linear_fp8(lp + "ff.ff.0.proj.weight", lp + "ff.ff.0.proj.bias", true, st);
           L.ff2_8 = pack_linear_fp8(lp + "ff.ff.2.weight", lp + "ff.ff.2.bias", false, st);
+          if (fold_ln8) {
+            // ff_norm folded into FF-in as in the 16-bit modes: gamma is multiplied in BEFORE the block quantisation, the
+            // row sums are those of the dequantised bytes (what the MFMAs multiply), beta goes into the bias
+            const DevTensor& w = get(lp + "ff.ff.0.proj.weight");
+            Packed8& p = L.ff1f8;
+            p.N = L.ff1_8.N;
+            p.K = L.ff1_8.K;
+            p.w = (unsigned char*)dmalloc((size_t)p.N * p.K);
+            p.s = (unsigned char*)dmalloc((size_t)p.N * (p.K / 32));
+            launch_pack_weight_fp8(w.p, p.w, p.s, p.N, p.K, 1, st, L.g2);
+            L.ff1_colsum8 = (float*)dmalloc(sizeof(float) * p.N);
+            launch_fp8_row_sum(p.w, p.s, p.N, p.K, L.ff1_colsum8, st);
+            p.bias = L.ff1_8.bias;
+            if (L.be2) {
+              float* tmp = (float*)dmalloc(sizeof(float) * p.N);
+              launch_bias_plus_wbeta(w.p, L.be2, maybe(lp + "ff.ff.0.proj.bias"), p.N, p.K, tmp, st);
+              p.bias = (float*)dmalloc(sizeof(float) * p.N);
+              launch_pack_bias_swiglu(tmp, p.bias, p.N, st);
+            }
+          }
           continue;
         }
         L.qkv = pack_linear(lp + "self_attn.to_qkv.weight", "", false, st);
@@ -991,13 +1015,16 @@ struct dsn_ctx {
     const char* sks = getenv("DSN_SKINNY_KS");  // development: split-K of the skinny N = D GEMMs (default 8)
     const int skinny_ks = sks ? std::max(1, std::min(atoi(sks), 8)) : 8;
     int fold_rows = 0;
-    if (fold_ln && use_panel_ok(D) && !skinny) {
+    if ((fold_ln || fold_ln8) && use_panel_ok(D) && !skinny) {
       for (int rounds = 1; rounds <= 4 && !fold_rows; ++rounds) {
         const int np = 256 * rounds / std::max(1, cdiv(D, 128));
         if (np >= 1 && cdiv(M, np) <= 80) fold_rows = cdiv(M, np);
       }
     }
-    op16_t* Xp = fold_rows ? wsbuf<op16_t>("dit_Xp", M * D) : nullptr;
+    op16_t* Xp = (fold_rows && !fp8) ? wsbuf<op16_t>("dit_Xp", M * D) : nullptr;
+    // (fp8: raw x' as e4m3 + block scales; NOT the to_out input buffer -- other column tiles still read those rows)
+    unsigned char* X8 = (fold_rows && fp8) ? wsbuf<unsigned char>("dit_X8", M * D) : nullptr;
+    unsigned char* SX8 = (fold_rows && fp8) ? wsbuf<unsigned char>("dit_SX8", M * D / 32) : nullptr;
     float* ST = fold_rows ? wsbuf<float>("dit_ST", M * (D / 64) * 2) : nullptr;
     const int rot = 32;  // max(dim_heads/2, 32) with 64-wide heads
     const bool new_rope = !ws.count("rope_cos_" + std::to_string(S));
@@ -1143,13 +1170,16 @@ struct dsn_ctx {
           d.resid = X;
           d.out_f32 = X;
           d.out_planes = Xp;
+          d.out_fp8 = X8;
+          d.out_fp8_scale = SX8;
           d.out_ps = M * D;
           d.stat_out = ST;
           d.stat_np = D / 64;
           static const bool out_mfast = getenv("DSN_OUT_MFAST") != nullptr;
           d.m_fast = out_mfast ? 1 : 0;  // an XCD's share walks ACROSS the 8 column tiles of a few row panels: the whole
                                          // 2 MB weight and 4 panels fit its L2 (m_fast = 1: every XCD re-fetches all of A)
-          run(d, st, 128);
+          if (fp8) run_fp8(d, st, 128);
+          else run(d, st, 128);
           pend_n = 0;
           pend_bias = nullptr;
         } else {
@@ -1183,14 +1213,14 @@ struct dsn_ctx {
         // FF-in through the row-panel kernel: ceil(M/272) equal row panels x 256-column tiles -- for the
         // benchmark shape (M = 2112 -> 8 panels of 264 rows, N = 8192) exactly 256 workgroups, one round.
         Tag tg(this, "dit.ff_in");
-        GemmDesc d = fp8 ? fp8_desc(A8, SA8, L.ff1_8, (int)M)
+        GemmDesc d = fp8 ? (fold_rows ? fp8_desc(X8, SX8, L.ff1f8, (int)M) : fp8_desc(A8, SA8, L.ff1_8, (int)M))
                          : (fold_rows ? base_desc(Xp, M * D, L.ff1f, 1, (int)M, (int)M)
                                       : base_desc(Ap, M * D, L.ff1, 1, (int)M, (int)M));
         d.swiglu = 1;
         if (fold_rows) {
           d.ln_stats = ST;
           d.ln_np = D / 64;
-          d.ln_colsum = L.ff1_colsum;
+          d.ln_colsum = fp8 ? L.ff1_colsum8 : L.ff1_colsum;
           d.ln_eps = 1e-5f;
         }
         if (fp8) {

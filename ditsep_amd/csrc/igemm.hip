@@ -167,16 +167,41 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
         if (n < d.N) {
           *reinterpret_cast<f32x4*>(d.out_f32 + (long)m * d.N + n) = v;
-          op16x4 hi, lo;
+          if constexpr ((EPI & EPI_FP8OUT) == 0) {
+            op16x4 hi, lo;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            op16_t h, l;
-            dsn_split(v[r], h, l, F16);
-            hi[r] = h;
-            lo[r] = l;
+            for (int r = 0; r < 4; ++r) {
+              op16_t h, l;
+              dsn_split(v[r], h, l, F16);
+              hi[r] = h;
+              lo[r] = l;
+            }
+            *reinterpret_cast<op16x4*>(d.out_planes + (long)m * d.N + n) = hi;
+            if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + (long)m * d.N + n) = lo;
           }
-          *reinterpret_cast<op16x4*>(d.out_planes + (long)m * d.N + n) = hi;
-          if (P == 2) *reinterpret_cast<op16x4*>(d.out_planes + d.out_ps + (long)m * d.N + n) = lo;
+        }
+      }
+      if constexpr ((EPI & EPI_FP8OUT) != 0) {
+        // raw x' as the fp8 (MX) operand of the folded FF-in: a 32-column scale block = a pair of column sub-tiles of
+        // this row across the 4 lane groups that share it (the partner lanes hold the same row: same branch)
+#pragma unroll
+        for (int tp = 0; tp < NT / 2; ++tp) {
+          float amax = 0.f;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(acc[2 * tp + u][tm][r]));
+          amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+          const int k = dsn_mx_exp(amax);
+          const float inv = dsn_pow2(-k);
+          const int nb = nw0 + tp * 32;
+          if (nb < d.N) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              *reinterpret_cast<unsigned*>(d.out_fp8 + (long)m * d.N + nb + u * 16 + nq) = dsn_fp8x4(acc[2 * tp + u][tm] * inv);
+            if ((lane >> 4) == 0) d.out_fp8_scale[(long)m * (d.N >> 5) + (nb >> 5)] = (unsigned char)(k + 127);
+          }
         }
       }
       s1 += __shfl_xor(s1, 16, 64);
@@ -197,7 +222,57 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
     }
     return;
   }
-  if constexpr ((EPI & EPI_LNFOLD) != 0) {
+  if constexpr ((EPI & EPI_LNFOLD) != 0 && (EPI & EPI_FP8OUT) != 0) {
+    // Folded-LayerNorm SwiGLU consumer with fp8 (MX) output: the wave's 64 packed columns are 32 output features = ONE
+    // scale block of a row (see the unfolded fp8 SwiGLU branch below)
+    static_assert(NT == 4, "fp8 SwiGLU epilogue expects 64 packed columns per wave");
+    if (nw0 >= d.N) return;
+    f32x4 cv[2], cg[2], bv[2], bg[2];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      const int np = nw0 + tp * 32;
+      cv[tp] = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + nq);
+      cg[tp] = *reinterpret_cast<const f32x4*>(d.ln_colsum + np + 16 + nq);
+      bv[tp] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bg[tp] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + np + 16 + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      dsn_touch(cv[tp]);
+      dsn_touch(cg[tp]);
+      dsn_touch(bv[tp]);
+      dsn_touch(bg[tp]);
+    }
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+      const int m = mw0 + tm * 16 + (lane & 15);
+      if (m >= m_end) continue;  // (the lanes 16 / 32 / 48 away hold the same row: the shuffles below stay convergent)
+      const float mu = ln_rows[2 * (m - ln_m0)], rs = ln_rows[2 * (m - ln_m0) + 1];
+      f32x4 h[2];
+      float amax = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        const f32x4 val = (acc[2 * tp][tm] - cv[tp] * mu) * rs + bv[tp];
+        const f32x4 gate = (acc[2 * tp + 1][tm] - cg[tp] * mu) * rs + bg[tp];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[tp][r] = val[r] * dsn_silu(gate[r]);
+          amax = fmaxf(amax, fabsf(h[tp][r]));
+        }
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int k = dsn_mx_exp(amax);
+      const float inv = dsn_pow2(-k);
+      const long orow = (long)m * (d.N >> 1);
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+        *reinterpret_cast<unsigned*>(d.out_fp8 + orow + (nw0 >> 1) + tp * 16 + nq) = dsn_fp8x4(h[tp] * inv);
+      if ((lane >> 4) == 0) d.out_fp8_scale[(long)m * (d.N >> 6) + (nw0 >> 6)] = (unsigned char)(k + 127);
+    }
+    return;
+  }
+  if constexpr ((EPI & EPI_LNFOLD) != 0 && (EPI & EPI_FP8OUT) == 0) {
     // Folded-LayerNorm SwiGLU consumer: LN(x') W^T = rstd (x' (W diag gamma)^T - mean colsum) + bias', then
     // value * silu(gate) -> operand planes [M][N/2].  Column vectors are loaded once, rows then stream out.
 #pragma unroll
@@ -1245,7 +1320,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_kernel(const Ge
 // glds per k-tile for the scale dwords of 64 staged rows (waves beyond the staged rows load a zero page), so the
 // counted vmcnt stays uniform; lane (r, q) then reads byte q of its row's dword.
 // ============================================================================
-template <int WM_, int WN_, int NST, int MT>
+template <int WM_, int WN_, int NST, int MT, int EPI = EPI_FP8OUT>
 __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(const GemmDesc d,
                                                                              const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [NST][A rows | W rows][64 pairs], then [NST][SROWS] u32
@@ -1358,6 +1433,40 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
   for (int s2 = 0; s2 < NST - 1; ++s2)
     if (s2 < nkt) issue(s2);
 
+  if constexpr ((EPI & EPI_STATS) != 0) {
+    // residual-stream producer (folded ff_norm, fp8 mode): the accumulators start from x (plain [M][N] fp32); the MFMA
+    // scales apply to the products only
+#pragma unroll
+    for (int tm = 0; tm < MTW; ++tm) {
+      const int m = m0 + my_row0 + tm * 16 + (lane & 15);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wave_n * 64 + tn * 16 + (lane >> 4) * 4;
+        if (tm < my_mt && m < m_end && n < d.N) acc[tn][tm] = *reinterpret_cast<const f32x4*>(d.resid + (long)m * d.N + n);
+      }
+    }
+  }
+  // folded LayerNorm: (mean, rstd) of the panel's rows from the producer's per-64-column partials (as in
+  // igemm_panel_kernel; the row length is the fp8 K = 2 * Cin) -> LDS behind the scale ring
+  float* const ln_rows = reinterpret_cast<float*>(slds + NST * SROWS);
+  if ((EPI & EPI_LNFOLD) && d.ln_stats) {
+    const float kcols = (float)(2 * d.Cin);
+    for (int r = tid; r < m_end - m0; r += NWAVES * 64) {
+      const f32x4* ps = reinterpret_cast<const f32x4*>(d.ln_stats + (long)(m0 + r) * d.ln_np * 2);
+      float msum = 0.f, m2 = 0.f, q = 0.f;
+      for (int p2 = 0; p2 < d.ln_np / 2; ++p2) {
+        const f32x4 v = ps[p2];
+        msum += v[0] + v[2];
+        m2 += v[1] + v[3];
+        q += v[0] * v[0] + v[2] * v[2];
+      }
+      const float mean = msum / (float)d.ln_np;
+      m2 += (kcols / (float)d.ln_np) * fmaxf(q - (float)d.ln_np * mean * mean, 0.f);
+      ln_rows[2 * r] = mean;
+      ln_rows[2 * r + 1] = rsqrtf(m2 / kcols + d.ln_eps);
+    }
+  }
+
   for (int i = 0; i < nkt; ++i) {
     const int younger = min(NST - 2, nkt - 1 - i);
     if (NST >= 3 && younger >= 1) {
@@ -1405,8 +1514,8 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
       sa = nsa;
     }
   }
-  epilogue_gen<1, 1, 4, MTW, EPI_FP8OUT>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64,
-                                         lane, z);
+  epilogue_gen<1, 1, 4, MTW, EPI>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z,
+                                  ((EPI & EPI_LNFOLD) && d.ln_stats) ? ln_rows : nullptr, m0);
 }
 
 
@@ -1715,20 +1824,21 @@ static hipError_t launch_panel_t(GemmDesc d, const op16_t* zp, hipStream_t strea
 }
 
 
-template <int WM_, int WN_, int NST, int MT>
+template <int WM_, int WN_, int NST, int MT, int EPI = EPI_FP8OUT>
 static hipError_t launch_panel_fp8_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   constexpr int TBN = WN_ * 64;
   d.tiles_m = cdiv(d.M, d.panel_rows);
   d.tiles_n = cdiv(d.N, TBN);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_fp8_kernel<WM_, WN_, NST, MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_panel_fp8_kernel<WM_, WN_, NST, MT, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int grid = d.tiles_m * d.tiles_n * d.ksplit;
-  const size_t smem = (size_t)NST * ((MT * 16 + TBN) * 64 * sizeof(op16_t) + ((MT * 16 + TBN + 63) / 64 + 1) * 64 * sizeof(unsigned));
+  const size_t smem = (size_t)NST * ((MT * 16 + TBN) * 64 * sizeof(op16_t) + ((MT * 16 + TBN + 63) / 64 + 1) * 64 * sizeof(unsigned)) +
+                      ((EPI & EPI_LNFOLD) ? MT * 16 * 2 * sizeof(float) : 0);
   if (smem > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((igemm_panel_fp8_kernel<WM_, WN_, NST, MT>), dim3(grid), dim3(WM_ * WN_ * 64), smem, stream, d, zp);
+  hipLaunchKernelGGL((igemm_panel_fp8_kernel<WM_, WN_, NST, MT, EPI>), dim3(grid), dim3(WM_ * WN_ * 64), smem, stream, d, zp);
   return hipGetLastError();
 }
 
@@ -1742,14 +1852,30 @@ hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t strea
     return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 64 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
+  // folded ff_norm: the producer (statistics + raw fp8 x') and the SwiGLU consumer, as in igemm_panel_launch
+  if (d.stat_out && (d.N % 64 != 0 || d.stat_np != d.N / 64 || d.swiglu || d.ksplit > 1 || !d.resid || !d.out_f32 ||
+                     !d.out_fp8 || !d.out_fp8_scale))
+    return hipErrorInvalidValue;
+  if (d.ln_stats && (!d.swiglu || !d.ln_colsum || d.ln_np <= 0 || (d.ln_np & 1) || !d.out_fp8 || !d.out_fp8_scale))
+    return hipErrorInvalidValue;
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-#define FCFG(MT_, WM_, W_, NS_) \
-  if (d.panel_rows <= MT_ * 16 && bn == W_ * 64) return launch_panel_fp8_t<WM_, W_, NS_, MT_>(d, zp, stream);
+#define FCFGE(MT_, WM_, W_, NS_, E_) \
+  if (d.panel_rows <= MT_ * 16 && bn == W_ * 64) return launch_panel_fp8_t<WM_, W_, NS_, MT_, E_>(d, zp, stream);
+#define FCFG(MT_, WM_, W_, NS_) FCFGE(MT_, WM_, W_, NS_, EPI_FP8OUT)
+  if (d.stat_out) {  // 66-row panels x 128 columns: to_out without split-K (one balanced round at M = 2112)
+    FCFGE(5, 4, 2, 4, EPI_STATS | EPI_FP8OUT)
+    return hipErrorInvalidValue;
+  }
+  if (d.ln_stats) {
+    FCFGE(7, 4, 4, 3, EPI_LNFOLD | EPI_FP8OUT) FCFGE(9, 2, 4, 3, EPI_LNFOLD | EPI_FP8OUT)
+    return hipErrorInvalidValue;
+  }
   // 16 waves only where the accumulators leave room under the 128-register cap; tall panels run 8 waves (a 272-row
   // x 256-column tile does not fit 256 registers per lane with 32-byte fragments: callers use <= 208 rows there)
   FCFG(7, 4, 4, 3) FCFG(9, 2, 4, 3) FCFG(9, 4, 2, 3) FCFG(13, 2, 4, 2) FCFG(13, 4, 2, 3) FCFG(17, 4, 2, 3)
 #undef FCFG
+#undef FCFGE
   return hipErrorInvalidValue;
 }
 

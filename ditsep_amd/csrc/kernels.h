@@ -96,9 +96,12 @@ void launch_bias_plus_wbeta(const float* W, const float* beta, const float* bias
                             hipStream_t s);
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t s);
 // Linear weight [N][K] fp32 (swiglu: rows interleaved as PACK_LINEAR_SWIGLU) -> fp8 e4m3 bytes [N][K] + E8M0 block
-// scales [N][K/32] (one per 32 consecutive K-elements); K % 32 == 0
+// scales [N][K/32] (one per 32 consecutive K-elements); K % 32 == 0.  colscale [K] (optional) is multiplied in before
+// quantisation (a LayerNorm gamma folded into the weight).
 void launch_pack_weight_fp8(const float* src, unsigned char* dst, unsigned char* scales, int N, int K, int swiglu,
-                            hipStream_t s);
+                            hipStream_t s, const float* colscale = nullptr);
+// out[n] = sum_k of the dequantised fp8 (MX) row n: the folded LayerNorm's mean * colsum term for fp8 weights
+void launch_fp8_row_sum(const unsigned char* w, const unsigned char* scales, int N, int K, float* out, hipStream_t s);
 // snake parameters: alpha -> exp(alpha), beta -> 1/(exp(beta)+1e-9)
 void launch_snake_params(const float* alpha, const float* beta, float* a_out, float* ib_out, int C,
                          hipStream_t s);

@@ -848,8 +848,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const float* _
 }
 
 // one thread per (row, 32-element block): amax -> E8M0 scale -> 32 saturated e4m3 bytes
+// colscale (optional): per-k factor multiplied in BEFORE quantisation (LayerNorm gamma folded into the weight)
 __global__ void pack_weight_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
-                                       unsigned char* __restrict__ scales, int N, int K, int swiglu) {
+                                       unsigned char* __restrict__ scales, int N, int K, int swiglu,
+                                       const float* __restrict__ colscale) {
   const int kb = K >> 5;
   const long total = (long)N * kb;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -865,6 +867,7 @@ __global__ void pack_weight_fp8_kernel(const float* __restrict__ src, unsigned c
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] = sp[j];
+      if (colscale) v[j] *= *reinterpret_cast<const f32x4*>(colscale + b * 32 + j * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(v[j][r]));
     }
@@ -888,6 +891,23 @@ __global__ void packed_row_sum_kernel(const op16_t* __restrict__ w, long ps, int
   for (int k = lane; k < K; k += 64) {
     s += from_op16(w[(long)row * K + k], f16);
     if (PL_COUNT(planes) == 2) s += from_op16(w[ps + (long)row * K + k], f16);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+// The same for an fp8 (MX) packed weight: sum_k of the DEQUANTISED bytes, e4m3 * 2^(scale - 127).  One wave per row;
+// lane l sums the dwords l, l + 64, ... of the row (fixed order: every call returns the same bits).
+__global__ void fp8_row_sum_kernel(const unsigned char* __restrict__ w, const unsigned char* __restrict__ scales, int N,
+                                   int K, float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k4 = lane; k4 < (K >> 2); k4 += 64) {
+    const int word = reinterpret_cast<const int*>(w + (long)row * K)[k4];
+    const float sc = dsn_pow2((int)scales[(long)row * (K >> 5) + (k4 >> 3)] - 127);
+    s += sc * ((__builtin_amdgcn_cvt_f32_fp8(word, 0) + __builtin_amdgcn_cvt_f32_fp8(word, 1)) +
+               (__builtin_amdgcn_cvt_f32_fp8(word, 2) + __builtin_amdgcn_cvt_f32_fp8(word, 3)));
   }
   s = wave_sum(s);
   if (lane == 0) out[row] = s;
@@ -1096,9 +1116,12 @@ void launch_bias_plus_wbeta(const float* W, const float* beta, const float* bias
   hipLaunchKernelGGL(bias_plus_wbeta_kernel, dim3(cdiv(N, 4)), dim3(TPB), 0, st, W, beta, bias, N, K, out);
 }
 void launch_pack_weight_fp8(const float* src, unsigned char* dst, unsigned char* scales, int N, int K, int swiglu,
-                            hipStream_t st) {
+                            hipStream_t st, const float* colscale) {
   hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3(grid_for((long)N * (K >> 5))), dim3(TPB), 0, st, src, dst, scales, N, K,
-                     swiglu);
+                     swiglu, colscale);
+}
+void launch_fp8_row_sum(const unsigned char* w, const unsigned char* scales, int N, int K, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(fp8_row_sum_kernel, dim3(cdiv(N, 4)), dim3(TPB), 0, st, w, scales, N, K, out);
 }
 void launch_pack_bias_swiglu(const float* src, float* dst, int N, hipStream_t st) {
   hipLaunchKernelGGL(pack_bias_swiglu_kernel, dim3(grid_for(N)), dim3(TPB), 0, st, src, dst, N);

@@ -48,11 +48,13 @@ def apply_rope(t: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.T
 
 
 def dit_forward(sd: dict, cfg: DiTConfig, x: torch.Tensor, t: torch.Tensor,
-                concat_cond: torch.Tensor, matmul=None) -> torch.Tensor:
+                concat_cond: torch.Tensor, matmul=None, ff_in=None) -> torch.Tensor:
     """x [B, io, T], t [B], concat_cond [B, latent_dim, T] -> [B, io, T].
 
     `matmul(a, w)` (a [..., K], w [N, K] -> [..., N]) may be overridden to
     emulate reduced-precision GEMM operands; default is exact fp32.
+    `ff_in(h, layer_index)` (h [B, S, D] the residual stream -> [B, S, 2 * 4 D] = ff.0.proj(ff_norm(h)) with bias) may
+    be overridden to emulate a device mode that evaluates that pair in another algebraic form (tests only).
     """
     mm = matmul or (lambda a, w: a @ w.t())
     D, H, dh = cfg.embed_dim, cfg.num_heads, cfg.dim_heads
@@ -86,8 +88,11 @@ def dit_forward(sd: dict, cfg: DiTConfig, x: torch.Tensor, t: torch.Tensor,
         o = o.transpose(1, 2).reshape(B, S, D)
         h = h + mm(o, sd[p + "self_attn.to_out.weight"])
 
-        a = F.layer_norm(h, (D,), sd[p + "ff_norm.gamma"], sd.get(p + "ff_norm.beta"), 1e-5)
-        u = mm(a, sd[p + "ff.ff.0.proj.weight"]) + sd[p + "ff.ff.0.proj.bias"]
+        if ff_in is not None:
+            u = ff_in(h, i)
+        else:
+            a = F.layer_norm(h, (D,), sd[p + "ff_norm.gamma"], sd.get(p + "ff_norm.beta"), 1e-5)
+            u = mm(a, sd[p + "ff.ff.0.proj.weight"]) + sd[p + "ff.ff.0.proj.bias"]
         val, gate = u.chunk(2, dim=-1)
         u = val * F.silu(gate)
         h = h + mm(u, sd[p + "ff.ff.2.weight"]) + sd[p + "ff.ff.2.bias"]
@@ -101,11 +106,11 @@ def dit_forward(sd: dict, cfg: DiTConfig, x: torch.Tensor, t: torch.Tensor,
 class DiTScore:
     """score_fn(xt, t, mix) adapter around dit_forward."""
 
-    def __init__(self, sd: dict, cfg: DiTConfig, matmul=None):
-        self.sd, self.cfg, self.matmul = sd, cfg, matmul
+    def __init__(self, sd: dict, cfg: DiTConfig, matmul=None, ff_in=None):
+        self.sd, self.cfg, self.matmul, self.ff_in = sd, cfg, matmul, ff_in
 
     def __call__(self, xt, t, mix):
         B, n, Dl, T = xt.shape
         out = dit_forward(self.sd, self.cfg, xt.reshape(B, n * Dl, T), t,
-                          mix.reshape(B, Dl, T), self.matmul)
+                          mix.reshape(B, Dl, T), self.matmul, self.ff_in)
         return out.reshape(B, n, Dl, T)
