@@ -1239,7 +1239,9 @@ struct dsn_ctx {
           d.panel_rows = short_panel ? panel_rows_for(cdiv(4 * D * 2, 256)) : (cdiv(M, np) + 7) / 8 * 8;
         }
         if (fp8) {
-          d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256), 144);  // 256-column fp8 tiles: at most 9 row sub-tiles
+          // 256-column fp8 tiles up to 17 row sub-tiles (8 waves x 256 registers, branch-free main loop): one round at C2
+          static const char* f8rows = getenv("DSN_FP8_FF1_ROWS");  // development: cap of the panel height (144: round 2)
+          d.panel_rows = panel_rows_for(cdiv(4 * D * 2, 256), f8rows ? atoi(f8rows) : 272);
           run_fp8(d, st, 256);
         } else if (skinny) {
           run(d, st, 0, true);

@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
   constexpr int SG = (ROWS + 63) / 64;             // 64-row scale groups that hold staged rows
   constexpr int SGW = (SG + NWAVES - 1) / NWAVES;  // scale groups per wave (uniform: tail slots load a zero page)
   constexpr int SROWS = (SG + 1) * 64;             // scale dwords per stage; slots >= SG land in the spare group
+  constexpr bool PF = MTW < 8;                     // A fragments one row sub-tile ahead of their MFMAs
   unsigned* const slds = reinterpret_cast<unsigned*>(lds + NST * STAGE_ELEMS);
 
   const int tid = threadIdx.x;
@@ -1370,46 +1371,49 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
   const int nkt = kt_end - kt_begin;
 
   const int rsub = lane / CPR, cpos = lane % CPR;
-  const op16_t* zsrc = zero_page + cpos * 8;
-  const op16_t* rptr[GPW];  // this lane's 16-byte slot of each staged row at k = 0 (rows outside M / N: the zero page)
+  // this lane's 16-byte slot of each staged row at k = 0, as a 32-bit element offset from the (wave-uniform) operand
+  // base.  Rows outside M / N are CLAMPED to the last valid row instead of routed to a zero page: they only feed
+  // accumulators of rows / columns the epilogue never stores, and a uniform base + 32-bit offset costs half the
+  // registers of a pointer per group (the 17-sub-tile tile needs them)
+  unsigned roff[GPW];  // (unsigned: base + zero-extended offset is the scalar-base addressing form of the load)
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave + gi * NWAVES;
     const bool is_a = g < AROWS / RPG;
     const int row = (is_a ? g : g - AROWS / RPG) * RPG + rsub;
     const int gchunk = cpos ^ swzk<TBK>(row);
-    const int idx = (is_a ? m0 : n0) + row;
-    const bool ok = g < GROUPS && (is_a ? idx < m_end : idx < d.N);
-    rptr[gi] = ok ? (is_a ? d.A : d.W) + (long)idx * Ktot + gchunk * 8 : nullptr;
+    const int idx = min((is_a ? m0 : n0) + row, (is_a ? m_end : d.N) - 1);
+    roff[gi] = (unsigned)(idx * Ktot + gchunk * 8) * 2u;  // BYTES (no shift between the zero-extension and the add)
   }
-  // scale loader: slot j of this wave = rows (wave + j*NWAVES)*64 + lane of the staged panel
-  const unsigned char* szero = reinterpret_cast<const unsigned char*>(zero_page) + (lane & 31) * 4;
-  const unsigned char* sptr[SGW];
+  // scale loader: slot j of this wave = rows (wave + j*NWAVES)*64 + lane of the staged panel (clamped the same way;
+  // slots past the staged rows re-read row 0 of the weight tile and land in the spare group)
+  unsigned soff[SGW];
+  bool s_a[SGW];
 #pragma unroll
   for (int j = 0; j < SGW; ++j) {
     const int srow = (wave + j * NWAVES) * 64 + lane;
     const bool s_is_a = srow < AROWS;
-    const int sidx = s_is_a ? m0 + srow : n0 + (srow - AROWS);
-    const bool s_ok = srow < ROWS && (s_is_a ? sidx < m_end : sidx < d.N);
-    sptr[j] = s_ok ? (s_is_a ? d.a_scale : d.w_scale) + (long)sidx * d.mx_kblocks : nullptr;
+    s_a[j] = s_is_a;
+    const int sidx = s_is_a ? min(m0 + srow, m_end - 1) : min(n0 + min(srow - AROWS, TBN - 1), d.N - 1);
+    soff[j] = (unsigned)(sidx * d.mx_kblocks);
   }
   int kt_abs = kt_begin;
 
   auto issue = [&](int stage) {
     op16_t* sbase = lds + stage * STAGE_ELEMS;
-    const long off = (long)kt_abs * TBK;
+    const unsigned off = (unsigned)(kt_abs * TBK) * 2u;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       if (gi < my_groups) {
         const int g = wave + gi * NWAVES;
-        const op16_t* gp = rptr[gi] ? rptr[gi] + off : zsrc;
+        const char* gp = reinterpret_cast<const char*>(g < AROWS / RPG ? d.A : d.W) + (off + roff[gi]);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                          (__attribute__((address_space(3))) void*)(sbase + g * RPG * TBK), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < SGW; ++j) {
-      const unsigned char* sp = sptr[j] ? sptr[j] + 4 * kt_abs : szero;
+      const unsigned char* sp = (s_a[j] ? d.a_scale : d.w_scale) + (soff[j] + (unsigned)(4 * kt_abs));
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)sp,
           (__attribute__((address_space(3))) void*)(slds + stage * SROWS + min(wave + j * NWAVES, SG) * 64), 4, 0, 0);
@@ -1499,22 +1503,30 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 1) void igemm_panel_fp8_kernel(cons
     for (int tm = 0; tm < MTW; ++tm) {
       op16x8 na0 = fa0, na1 = fa1;
       int nsa = sa;
-      if (tm + 1 < MTW) {
+      if (PF && tm + 1 < MTW) {
         na0 = *reinterpret_cast<const op16x8*>(base + a_row_off + (tm + 1) * 16 * TBK + c_lo);
         na1 = *reinterpret_cast<const op16x8*>(base + a_row_off + (tm + 1) * 16 * TBK + c_hi);
         nsa = sb[4 * (my_row0 + (tm + 1) * 16 + frow)];
       }
-      if (tm < my_mt) {
+      // (tall wave tiles run branch-free: a wave row's missing last sub-tile reads the rows that follow in LDS and its
+      // accumulators are never stored -- with the uniform branch hipcc spills fragments and accumulators in the loop)
+      if (!PF || tm < my_mt) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tn][tm] = mfma_mx8(fw0[tn], fw1[tn], fa0, fa1, acc[tn][tm], sw[tn], sa);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!PF && tm + 1 < MTW) {  // tall wave tiles: no registers for a second fragment pair
+        const int ao = a_row_off + (tm + 1) * 16 * TBK;
+        na0 = *reinterpret_cast<const op16x8*>(base + ao + c_lo);
+        na1 = *reinterpret_cast<const op16x8*>(base + ao + c_hi);
+        nsa = sb[4 * (my_row0 + (tm + 1) * 16 + frow)];
+      }
       fa0 = na0;
       fa1 = na1;
       sa = nsa;
     }
   }
-  epilogue_gen<1, 1, 4, MTW, EPI>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z,
+  epilogue_gen<1, 1, 4, MTW, EPI, LEAN_NO_NCSN>(d, acc, m0 + my_row0, min(m_end, m0 + my_row0 + my_mt * 16), n0 + wave_n * 64, lane, z,
                                   ((EPI & EPI_LNFOLD) && d.ln_stats) ? ln_rows : nullptr, m0);
 }
 
@@ -1848,7 +1860,7 @@ hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t strea
   // plain row-major GEMM only: one "batch item" of M rows, one tap, K = 2 * Cin fp8 per row, whole 128-wide k-tiles
   if (!d.a_scale || !d.w_scale || d.taps != 1 || d.in_stride != 1 || d.in_pad != 0 || d.rows_per_b != d.M ||
       d.img_w > 0 || d.Cin % 64 != 0 || d.mx_kblocks != d.Cin / 16 || d.M <= 0 || d.N <= 0 || d.panel_rows <= 0 ||
-      d.panel_rows > 17 * 16)
+      d.panel_rows > 17 * 16 || (long)std::max(d.M, d.N) * d.Cin * 2 >= (1L << 32))
     return hipErrorInvalidValue;
   if (d.swiglu && (d.N % 64 != 0)) return hipErrorInvalidValue;
   if (d.ksplit > 1 && (!d.out_f32 || d.swiglu)) return hipErrorInvalidValue;
@@ -1869,11 +1881,13 @@ hipError_t igemm_panel_fp8_launch(const GemmDesc& din, int bn, hipStream_t strea
   }
   if (d.ln_stats) {
     FCFGE(7, 4, 4, 3, EPI_LNFOLD | EPI_FP8OUT) FCFGE(9, 2, 4, 3, EPI_LNFOLD | EPI_FP8OUT)
+    FCFGE(17, 2, 4, 2, EPI_LNFOLD | EPI_FP8OUT)
     return hipErrorInvalidValue;
   }
   // 16 waves only where the accumulators leave room under the 128-register cap; tall panels run 8 waves (a 272-row
   // x 256-column tile does not fit 256 registers per lane with 32-byte fragments: callers use <= 208 rows there)
   FCFG(7, 4, 4, 3) FCFG(9, 2, 4, 3) FCFG(9, 4, 2, 3) FCFG(13, 2, 4, 2) FCFG(13, 4, 2, 3) FCFG(17, 4, 2, 3)
+  FCFG(17, 2, 4, 2)
 #undef FCFG
 #undef FCFGE
   return hipErrorInvalidValue;
