@@ -172,9 +172,11 @@ def roofline_rows(prof, fp8_sites=()):
     return rows
 
 
-def measure_c5(engine, dcfg, dev, steps=2, batch=8):
+def measure_c5(engine, dcfg, dev, steps=2, batch=16):
     """BASELINE config 5 shape on one GPU: 30 s mixtures at 16 kHz (T = 235 latent frames, 236 tokens), N = 30 +
-    1 corrector, hipGraph-captured sampler loop + plain decode; `batch` mixtures per step."""
+    1 corrector, hipGraph-captured sampler loop + plain decode; `batch` mixtures per step (BASELINE names no batch for
+    this config; 16 x 236 = 3776 token rows is about the row count of the C2 step -- scripts/c5_batch_sweep.py:
+    fp16 31.7 / 39.3 / 42.2 utt/s and fp8 36.3 / 46.3 / 50.6 at batch 8 / 16 / 32)."""
     import torch
     from ditsep_amd import synthetic
     L5 = 30 * FS
