@@ -130,6 +130,30 @@ struct dsn_ctx {
   bool fold_ln = false;  // ff_norm folded into FF-in, to_out without split-K writing the residual stream itself
   bool finalized = false;
   bool use_graphs = false;
+  // producer-finished GroupNorm (GemmDesc::gnf_out): host-mapped give-up flag of its waits; counters per (row tiles per
+  // image) value, zeroed once -- they only grow
+  int* fin_err_host = nullptr;
+  int* fin_err_dev = nullptr;
+  std::map<int, std::pair<unsigned*, long>> gnf_sync;
+  unsigned* gnf_counters(int nper, long count, hipStream_t st) {
+    if (!fin_err_host) {
+      HIPCHK(hipHostMalloc((void**)&fin_err_host, sizeof(int), hipHostMallocMapped));
+      *fin_err_host = 0;
+      HIPCHK(hipHostGetDevicePointer((void**)&fin_err_dev, fin_err_host, 0));
+    }
+    auto& c = gnf_sync[nper];
+    if (!c.first || c.second < count) {
+      if (c.first) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(c.first));
+      }
+      c.second = std::max(count, 1024L);
+      HIPCHK(hipMalloc((void**)&c.first, c.second * sizeof(unsigned)));
+      HIPCHK(hipMemsetAsync(c.first, 0, c.second * sizeof(unsigned), st));
+      ++ws_epoch;  // (first use is an eager warm-up call, never a capture)
+    }
+    return c.first;
+  }
   double hbm_ms = 0, hbm_bytes = 0;  // HBM-bound launches of the last profiled region (dsn_profile_hbm)
   int64_t hbm_launches = 0;
   std::map<std::string, DevTensor> raw;
@@ -1839,6 +1863,11 @@ int guarded(dsn_ctx* ctx, F&& f) {
   if (!ctx) return DSN_EINVAL;
   try {
     HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (ctx->fin_err_host && *ctx->fin_err_host) {
+      *ctx->fin_err_host = 0;
+      fail(DSN_EHIP, "a GroupNorm hand-off wait of an earlier call gave up (the workgroups of one conv were not resident "
+                     "together): that call's results are invalid; DSN_NO_GN_FIN=1 selects the separate GroupNorm pass");
+    }
     f();
     return DSN_OK;
   } catch (const Err& e) {
@@ -1897,6 +1926,8 @@ void dsn_destroy(dsn_ctx* ctx) {
   for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& kv : ctx->ws) (void)hipFree(kv.second.first);
+  for (auto& kv : ctx->gnf_sync) (void)hipFree(kv.second.first);
+  if (ctx->fin_err_host) (void)hipHostFree(ctx->fin_err_host);
   delete ctx;
 }
 

@@ -99,6 +99,18 @@ struct GemmDesc {
   float ln_eps;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
   int panel_wm;    // row-panel kernel: wave rows (0 / 4: 4 x WN waves; 2: the 8-wave variants, 256-column tiles)
+  // GroupNorm finished by the producing conv (igemm_halo3x3_kernel, gnf_out != null; needs gn_stats): the row-tile
+  // workgroups of an image publish their slice partials write-through, meet at the (image, column tile) counter, combine
+  // the image's partials exactly as gn_apply_kernel does, and store silu(GroupNorm(out)) as the operand plane of the next
+  // conv straight from their accumulators -- the fp32 tensor is never written and the gn_apply launch is not needed.
+  // All workgroups of the grid must be resident together (igemm_halo3x3_gnfin_ok).
+  op16_t* gnf_out;           // [B * rows_per_b][N] 16-bit plane
+  const float* gnf_gamma;    // [N]
+  const float* gnf_beta;     // [N]
+  unsigned* gnf_sync;        // [B * tiles_n] counters, only ever incremented (zeroed once at allocation)
+  int* gnf_err;              // host-visible flag, set when a wait gave up
+  float gnf_eps;
+  int gnf_silu;
   int cfg_bm, cfg_bn, cfg_nst, cfg_bk;  // explicit tile configuration for igemm2_launch (0 = heuristic)
   int dbg;         // development: 1 = skip in-loop glds (compute only), 2 = skip MFMAs (staging only)
   int m_fast;      // tile order inside an XCD's share: 1 = row panels fastest (few rows, many columns)
@@ -114,6 +126,8 @@ hipError_t igemm_slab_epilogue_launch(const GemmDesc& d, int pl, const float* sl
                                       hipStream_t stream);
 // halo-resident 3x3 conv (single-plane modes, W <= 32, H*W % 256 == 0); hipErrorNotSupported when not eligible
 hipError_t igemm_halo3x3_launch(const GemmDesc& d, int pl, hipStream_t stream);
+// can `d` (with gnf_out set) run as a producer-finished GroupNorm conv: halo-kernel eligible and one resident round?
+bool igemm_halo3x3_gnfin_ok(const GemmDesc& d, int pl);
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);

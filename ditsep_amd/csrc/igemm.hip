@@ -530,6 +530,12 @@ __device__ __forceinline__ void epilogue_gen(const GemmDesc& d_arg, f32x4 (&acc)
 #undef DSN_GN_MERGE
       const int n = nw0 + tn * 16 + nq;
       if ((lane & 15) == 0 && n < d.N) {
+        if (!(LEAN & LEAN_NO_NCSN) && d.gnf_out) {
+          // read again in THIS kernel by the other row tiles of the image (igemm_halo3x3_kernel): write-through stores
+          float* sp = d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2;
+          __hip_atomic_store(sp, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp + 1, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
         *reinterpret_cast<float2*>(d.gn_stats + ((((long)b * S + slice) * (d.N >> 2)) + (n >> 2)) * 2) = float2{mean, m2};
         if (d.gn_stats2)
           *reinterpret_cast<float2*>(d.gn_stats2 + ((((long)b * S + slice) * d.gn_nq2) + d.gn_qoff2 + (n >> 2)) * 2) =
@@ -1108,6 +1114,96 @@ __global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kerne
     for (int bb = 0; bb < 4; ++bb) asm volatile("" ::"v"(acc[a][bb]));
 #else
   epilogue_gen<1, F16, 4, 4, 0, LEAN_NO_DIT | LEAN_SEEDED>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane, 0);
+  if (d.gnf_out) {
+    // ---- GroupNorm finished here (GemmDesc::gnf_out; the epilogue above stored nothing but this tile's slice partials,
+    // write-through).  Hand-off as in MI355X_MICROARCH.md, "inter-workgroup visibility", write-through form: every storing
+    // wave drains its stores, workgroup barrier, one lane adds to the (image, column tile) counter and polls it until the
+    // image's HW / TBM row tiles have added, barrier, then every load of partials is an sc1 load.  The counter only
+    // grows (target = next multiple above the value the add returned): nothing to reset between graph replays.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nper = HW / TBM;
+    if (tid == 0) {
+      unsigned* cnt = d.gnf_sync + (long)b * d.tiles_n + tile_n;
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (old / (unsigned)nper + 1u) * (unsigned)nper;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if (spins > (1 << 21) || ((spins & 1023) == 0 && __hip_atomic_load(d.gnf_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+          __hip_atomic_store(d.gnf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (host: error on the next call)
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // (mean, rstd) of the groups of this column tile -> LDS (the ring is free).  The combine is gn_apply_kernel's, lane
+    // for lane -- TPG lanes per group, lane-local sums in index order, xor tree; its block is 256 threads wide, which
+    // fixes TPG -- so both paths normalise with the same bits.
+    float* const gm = reinterpret_cast<float*>(lds);
+    float* const gr = gm + 64;
+    const int C = d.N, nq_all = C >> 2;
+    const int G = min(C >> 2, 32), cpg = C / G, qpg = cpg >> 2;
+    const int S = HW >> 6;
+    int tpg = 1;
+    while (tpg < 64 && G * tpg * 2 <= 256) tpg *= 2;
+    const int ngt = min(TBN, C - n0) / cpg;  // groups of this column tile
+    {
+      const int gl = tid / tpg, sub = tid - gl * tpg;
+      const bool live = gl < ngt;
+      const float* sp = d.gn_stats + ((long)b * S * nq_all + (long)(n0 / cpg + (live ? gl : 0)) * qpg) * 2;
+      const int items = S * qpg;
+      const float cnt = 256.f;  // 64 rows x 4 channels per partial (whole slices: HW % 64 == 0)
+      float wsum = 0.f;
+      if (live)
+        for (int it = sub; it < items; it += tpg) {
+          const int sl = it / qpg, q = it - sl * qpg;
+          wsum += cnt * __hip_atomic_load(sp + ((long)sl * nq_all + q) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      for (int o = tpg >> 1; o >= 1; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+      const float ntot = (float)HW * (float)cpg;
+      const float mean = wsum / ntot;
+      float m2 = 0.f;
+      if (live)
+        for (int it = sub; it < items; it += tpg) {
+          const int sl = it / qpg, q = it - sl * qpg;
+          const float* pp = sp + ((long)sl * nq_all + q) * 2;
+          const float px = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float py = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float dm = px - mean;
+          m2 += py + cnt * dm * dm;
+        }
+      for (int o = tpg >> 1; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+      if (live && sub == 0) {
+        gm[gl] = mean;
+        gr[gl] = rsqrtf(m2 / ntot + d.gnf_eps);
+      }
+    }
+    __syncthreads();
+    const int nqc = (lane >> 4) * 4;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = n0 + wn * 64 + tn * 16 + nqc;
+      if (n >= C) continue;
+      const int gl = (n - n0) / cpg;
+      const float mean = gm[gl], rstd = gr[gl];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(d.gnf_gamma + n);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(d.gnf_beta + n);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+        const f32x4 v = acc[tn][tm] * d.out_scale;
+        op16x4 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = (v[k] - mean) * rstd * ga[k] + be[k];
+          h[k] = to_op16(d.gnf_silu ? dsn_silu(t) : t, F16);
+        }
+        *reinterpret_cast<op16x4*>(d.gnf_out + (long)m * C + n) = h;
+      }
+    }
+  }
 #endif
 }
 
@@ -1687,9 +1783,49 @@ static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream
                      stream, d, zp);
   return hipGetLastError();
 }
+// which halo variant runs `d`: 256 (8 waves, 256-row tiles), 128 (4 waves), 0 = not eligible
+static int halo_variant(const GemmDesc& d, int pl) {
+  if (PL_COUNT(pl) != 1 || d.img_w <= 0 || d.img_w > 32 || d.taps != 9 || d.Cin % 32 != 0 || d.in_stride != 1 ||
+      d.ksplit > 1 || d.swiglu || d.rows_per_b % 256 != 0 || d.rows_per_b != d.img_w * d.img_h || d.M % 256 != 0 ||
+      d.in_pad != 0)
+    return 0;
+  return (long)(d.M / 256) * cdiv(d.N, 128) >= 2 * 256 ? 256 : 128;
+}
+template <int F16, int TBM, int MINW>
+static int halo_resident_blocks() {
+  constexpr int HRMAX = ((TBM + 2 * 33 + 15) / 16) * 16;
+  const size_t smem = (size_t)(2 * HRMAX * 32 + 4 * 128 * 32 + 16 * 32) * sizeof(op16_t);
+  static std::atomic<unsigned long long> attr{0};
+  if (dsn_first_use_on_device(attr))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM, MINW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_halo3x3_kernel<F16, TBM, MINW>, (TBM / 64) * 2 * 64,
+                                                   smem) != hipSuccess ||
+      hipGetDeviceProperties(&prop, dsn_current_device()) != hipSuccess)
+    return 0;
+  return per_cu * prop.multiProcessorCount;
+}
+bool igemm_halo3x3_gnfin_ok(const GemmDesc& d, int pl) {
+  const bool off = getenv("DSN_NO_GN_FIN") != nullptr || getenv("DSN_NO_HALO") != nullptr;  // (per call: tests flip it)
+  const int v = halo_variant(d, pl);
+  if (off || !v || !d.gn_stats || d.N % 32 != 0 || d.N > 1024 || d.rows_per_b % v != 0 || d.out_scale != 1.f) return false;
+  const int G = std::min(d.N / 4, 32), cpg = d.N / G;
+  if (cpg % 4 != 0 || 128 % cpg != 0) return false;  // groups made of whole quads, never across a column tile
+  static int cap[2][2] = {{-1, -1}, {-1, -1}};
+  int& c = cap[PL_F16(pl) ? 1 : 0][v == 256 ? 1 : 0];
+  if (c < 0)
+    c = v == 256 ? (PL_F16(pl) ? halo_resident_blocks<1, 256, 4>() : halo_resident_blocks<0, 256, 4>())
+                 : (PL_F16(pl) ? halo_resident_blocks<1, 128, 1>() : halo_resident_blocks<0, 128, 1>());
+  return (long)(d.M / v) * cdiv(d.N, 128) <= c;  // every workgroup resident at once: they wait for each other
+}
 hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream) {
   const int planes = PL_COUNT(pl), f16 = PL_F16(pl);
   const GemmDesc& d = din;
+  if (d.gnf_out && (!igemm_halo3x3_gnfin_ok(d, pl) || !d.gnf_gamma || !d.gnf_beta || !d.gnf_sync || !d.gnf_err ||
+                    d.out_f32 || d.out_planes))
+    return hipErrorInvalidValue;
   // 128-row images (NCSN++ level 2, 128 workgroups of 4 waves) measured slower than igemm2's 128 x 128 x BK 64 tiles
   // (62 vs 55 us): not routed here
   if (planes != 1 || d.img_w <= 0 || d.img_w > 32 || d.taps != 9 || d.Cin % 32 != 0 || d.in_stride != 1 ||
@@ -1775,6 +1911,7 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
     const hipError_t e = igemm_halo3x3_launch(d, pl, stream);
     if (e != hipErrorNotSupported) return e;
   }
+  if (d.gnf_out) return hipErrorInvalidValue;  // (only the halo kernel finishes a GroupNorm: igemm_halo3x3_gnfin_ok)
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
   auto tiles = [&](int tm, int tn) { return (long)cdiv(d.M, tm) * cdiv(d.N, tn) * std::max(d.ksplit, 1); };

@@ -293,6 +293,28 @@ def test_ncsnpp_groupnorm_epilogue_partials_describe_their_tensor(ncsn_models):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [64, 8])
+def test_ncsnpp_producer_finished_groupnorm_is_bit_identical(ncsn_models, B, monkeypatch):
+    """GroupNorm_1 of a ResnetBlockBigGANpp finished by the conv that feeds it (igemm_halo3x3_kernel, GemmDesc::gnf_out:
+    slice partials handed over between the row-tile workgroups of an image inside the launch, silu(GroupNorm(h)) written
+    from the accumulators, no fp32 h, no gn_apply launch) against the separate statistics + apply pass
+    (DSN_NO_GN_FIN=1): same combine order, same expression -> the same bits, launch after launch."""
+    ncfg, vcfg, nsd, vsd = ncsn_models
+    xt, t, mix = _score_inputs(B, T32, 91 + B)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DSN_NO_GN_FIN", "1")
+        eng = make_engine(ncfg=ncfg, nsd=nsd, precision=FP16)
+        o = eng.score(xt, t, mix)
+        assert torch.isfinite(o).all()
+        for _ in range(3):
+            assert torch.equal(eng.score(xt, t, mix), o)
+        outs.append(o.clone())
+        eng.close()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 def test_ncsnpp_c2_batch64_chain_n30_vs_oracle(ncsn_models):
     """The reference's literal drop-in (LatentScoreModelNCSNpp) at the C2 batch: N = 30 chain + decode at B = 64,
     fp16, graphs on; items 0 / 31 / 63 against the CPU oracle under the north-star bound."""
