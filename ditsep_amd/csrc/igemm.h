@@ -99,6 +99,15 @@ struct GemmDesc {
   float ln_eps;
   int panel_rows;  // row-panel kernel only: rows per workgroup (<= 272)
   int panel_wm;    // row-panel kernel: wave rows (0 / 4: 4 x WN waves; 2: the 8-wave variants, 256-column tiles)
+  // 1x1 shortcut conv accumulated into the same tile before the 3x3 taps (igemm_halo3x3_kernel, sc_A != null): the
+  // NIN shortcut of a ResnetBlockBigGANpp, out = (Conv_1(a1) + Conv_2(x)) / sqrt 2, without the fp32 round trip of
+  // Conv_2's output and without its launch.  sc_A: planes [B][rows_per_b][sc_row_elems] (first sc_Cin channels used),
+  // sc_W: packed [N][sc_Cin], sc_bias [N] (added with the other biases; null: none).
+  const op16_t* sc_A;
+  const op16_t* sc_W;
+  const float* sc_bias;
+  int sc_Cin, sc_row_elems;
+  long sc_bstride;
   // GroupNorm finished by the producing conv (igemm_halo3x3_kernel, gnf_out != null; needs gn_stats): the row-tile
   // workgroups of an image publish their slice partials write-through, meet at the (image, column tile) counter, combine
   // the image's partials exactly as gn_apply_kernel does, and store silu(GroupNorm(out)) as the operand plane of the next
@@ -128,6 +137,8 @@ hipError_t igemm_slab_epilogue_launch(const GemmDesc& d, int pl, const float* sl
 hipError_t igemm_halo3x3_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // can `d` (with gnf_out set) run as a producer-finished GroupNorm conv: halo-kernel eligible and one resident round?
 bool igemm_halo3x3_gnfin_ok(const GemmDesc& d, int pl);
+// will igemm2_launch run `d` on the halo kernel (the only one that takes sc_A)?
+bool igemm_halo3x3_eligible(const GemmDesc& d, int pl);
 // `pl` = DSN_PL(plane count, fp16 flag)
 // row-panel variant (igemm.hip): d.panel_rows rows x bn (128 | 256) columns per workgroup
 hipError_t igemm_panel_launch(const GemmDesc& d, int pl, int bn, hipStream_t stream);

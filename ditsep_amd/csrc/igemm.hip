@@ -65,6 +65,7 @@ __device__ __forceinline__ void seed_acc(const GemmDesc& d, f32x4 (&acc)[NT][MT]
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (mok && n < d.N) {
         if (d.bias) v = *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod));
+        if (d.sc_bias) v += *reinterpret_cast<const f32x4*>(d.sc_bias + n);
         if (d.bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
         if (d.resid) v += *reinterpret_cast<const f32x4*>(d.resid + roff + n);
       }
@@ -951,7 +952,9 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / WTN) * 64, 1) void igemm2_kerne
 // of chunk c, right before that iteration's weight tile, so for the next NSTW-2 iterations it is YOUNGER than the
 // weight tile being waited for and the allowed outstanding count is raised by its (wave-uniform) instruction count.
 // ============================================================================
-template <int F16, int TBM, int MINW>
+// SC = 1: the variant that accumulates a 1x1 shortcut conv first (GemmDesc::sc_A) -- its own instantiation, so that the
+// plain convs keep their register allocation
+template <int F16, int TBM, int MINW, int SC = 0>
 __global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kernel(const GemmDesc d,
                                                                                 const op16_t* __restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) op16_t lds[];  // [2][HRMAX][32] halo | [NSTW][128][32] weights | dummy
@@ -984,8 +987,75 @@ __global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kerne
   const int nchunks = d.Cin / CK;
   const int nkt = 9 * nchunks;
 
-  // ---- loader state ----
+  f32x4 acc[4][4];
+  seed_acc<4, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane);  // before any glds: these loads land first (in order)
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int w_off = (wn * 64 + frow) * CK + ((fchunk ^ swzk<32>(frow)) * 8);
   const int rsub = lane >> 2, cpos = lane & 3;
+  // (the shortcut runs BEFORE the 3x3 loader state is set up: both live at once spilled 39 registers under the cap)
+  if constexpr (SC != 0) {
+    // ---- 1x1 shortcut conv (GemmDesc::sc_A) accumulated first: per 32-channel chunk the tile's own TBM rows (no halo)
+    // and a [128][32] weight tile, two stages (the halo buffers / weight slots 0 and 1), the plain protocol -- wait for
+    // the one stage in flight, barrier, issue the next, multiply.  ~0.5 us per chunk against a launch + an fp32
+    // round trip of the shortcut's output.
+    constexpr int AG = (TBM / 16) / NWAVES;  // row groups of 16 per wave
+    const int nch2 = d.sc_Cin / CK;
+    const op16_t* asrc[AG];
+#pragma unroll
+    for (int gi = 0; gi < AG; ++gi) {
+      const int h = (wave * AG + gi) * 16 + rsub;
+      asrc[gi] = d.sc_A + (long)b * d.sc_bstride + (long)(j0 + h) * d.sc_row_elems + ((cpos ^ swzk<32>(h)) << 3);
+    }
+    const op16_t* w2src[GW];
+    int w2step[GW];
+#pragma unroll
+    for (int gi = 0; gi < GW; ++gi) {
+      const int g = wave * GW + gi;
+      const int row = g * 16 + rsub;
+      const bool ok = g < TBN / 16 && n0 + row < d.N;
+      w2src[gi] = ok ? d.sc_W + (long)(n0 + row) * d.sc_Cin + ((cpos ^ swzk<32>(row)) << 3) : zero_page + cpos * 8;
+      w2step[gi] = ok ? CK : 0;
+    }
+    auto issue2 = [&](int cc) {
+      op16_t* ab = (cc & 1) ? hbuf + HBUF : hbuf;
+      op16_t* wb2 = wring + (cc & 1) * WBUF;
+#pragma unroll
+      for (int gi = 0; gi < AG; ++gi)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[gi] + (long)cc * CK),
+                                         (__attribute__((address_space(3))) void*)(ab + (wave * AG + gi) * 16 * CK), 16, 0, 0);
+#pragma unroll
+      for (int gi = 0; gi < GW; ++gi) {
+        const int g = wave * GW + gi;
+        op16_t* dst = g < TBN / 16 ? wb2 + g * 16 * CK : dummy;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w2src[gi] + (long)cc * w2step[gi]),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    issue2(0);
+    for (int cc = 0; cc < nch2; ++cc) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (cc + 1 < nch2) issue2(cc + 1);
+      const op16_t* ab = (cc & 1) ? hbuf + HBUF : hbuf;
+      const op16_t* wb2 = wring + (cc & 1) * WBUF;
+      const int r0 = wm * 64 + frow;  // +16 per sub-tile keeps the swizzle
+      const int a_off2 = r0 * CK + ((fchunk ^ swzk<32>(r0)) * 8);
+      op16x8 fa[4], fw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fa[k] = *reinterpret_cast<const op16x8*>(ab + a_off2 + k * 16 * CK);
+        fw[k] = *reinterpret_cast<const op16x8*>(wb2 + w_off + k * 16 * CK);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma16<F16>(fw[tn], fa[tm], acc[tn][tm]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has read the last stage: the 3x3 prologue may overwrite both
+  }
+  // ---- loader state ----
   const op16_t* hsrc[HGW];
   int hstep[HGW];
   op16_t* hdst[HGW];
@@ -1039,11 +1109,6 @@ __global__ __launch_bounds__((TBM / 64) * 2 * 64, MINW) void igemm_halo3x3_kerne
     }
   };
 
-  f32x4 acc[4][4];
-  seed_acc<4, 4>(d, acc, m0 + wm * 64, d.M, n0 + wn * 64, lane);  // before any glds: these loads land first (in order)
-
-  const int frow = lane & 15, fchunk = lane >> 4;
-  const int w_off = (wn * 64 + frow) * CK + ((fchunk ^ swzk<32>(frow)) * 8);
   // x-border flags of this lane's 4 output rows (row sub-tiles tm): bit tm of xl / xr
   unsigned xl = 0, xr = 0;
 #pragma unroll
@@ -1768,7 +1833,7 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
 // halo-resident 3x3 conv: eligibility + launch (hipErrorNotSupported = not eligible, caller falls back)
 // MINW = 4: registers capped at 128 so that two 8-wave workgroups share a CU (123 VGPRs, no spills since the GroupNorm
 // partials are taken in one pass); MINW = 1 for the 4-wave 128-row variant.
-template <int F16, int TBM, int MINW>
+template <int F16, int TBM, int MINW, int SC = 0>
 static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream) {
   d.tiles_m = d.M / TBM;
   d.tiles_n = cdiv(d.N, 128);
@@ -1776,10 +1841,10 @@ static hipError_t launch_halo_t(GemmDesc d, const op16_t* zp, hipStream_t stream
   const size_t smem = (size_t)(2 * HRMAX * 32 + 4 * 128 * 32 + 16 * 32) * sizeof(op16_t);
   static std::atomic<unsigned long long> attr{0};
   if (dsn_first_use_on_device(attr)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM, MINW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo3x3_kernel<F16, TBM, MINW, SC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((igemm_halo3x3_kernel<F16, TBM, MINW>), dim3(d.tiles_m * d.tiles_n), dim3((TBM / 64) * 2 * 64), smem,
+  hipLaunchKernelGGL((igemm_halo3x3_kernel<F16, TBM, MINW, SC>), dim3(d.tiles_m * d.tiles_n), dim3((TBM / 64) * 2 * 64), smem,
                      stream, d, zp);
   return hipGetLastError();
 }
@@ -1807,6 +1872,9 @@ static int halo_resident_blocks() {
     return 0;
   return per_cu * prop.multiProcessorCount;
 }
+bool igemm_halo3x3_eligible(const GemmDesc& d, int pl) {
+  return getenv("DSN_NO_HALO") == nullptr && halo_variant(d, pl) != 0;
+}
 bool igemm_halo3x3_gnfin_ok(const GemmDesc& d, int pl) {
   const bool off = getenv("DSN_NO_GN_FIN") != nullptr || getenv("DSN_NO_HALO") != nullptr;  // (per call: tests flip it)
   const int v = halo_variant(d, pl);
@@ -1826,6 +1894,7 @@ hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream)
   if (d.gnf_out && (!igemm_halo3x3_gnfin_ok(d, pl) || !d.gnf_gamma || !d.gnf_beta || !d.gnf_sync || !d.gnf_err ||
                     d.out_f32 || d.out_planes))
     return hipErrorInvalidValue;
+  if (d.sc_A && (!d.sc_W || d.sc_Cin < 32 || d.sc_Cin % 32 != 0 || d.sc_row_elems < d.sc_Cin)) return hipErrorInvalidValue;
   // 128-row images (NCSN++ level 2, 128 workgroups of 4 waves) measured slower than igemm2's 128 x 128 x BK 64 tiles
   // (62 vs 55 us): not routed here
   if (planes != 1 || d.img_w <= 0 || d.img_w > 32 || d.taps != 9 || d.Cin % 32 != 0 || d.in_stride != 1 ||
@@ -1835,6 +1904,10 @@ hipError_t igemm_halo3x3_launch(const GemmDesc& din, int pl, hipStream_t stream)
   const op16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
   const long wgs = (long)(d.M / 256) * cdiv(d.N, 128);
+  if (d.sc_A) {
+    if (wgs >= 2 * 256) return f16 ? launch_halo_t<1, 256, 4, 1>(d, zp, stream) : launch_halo_t<0, 256, 4, 1>(d, zp, stream);
+    return f16 ? launch_halo_t<1, 128, 1, 1>(d, zp, stream) : launch_halo_t<0, 128, 1, 1>(d, zp, stream);
+  }
   if (wgs >= 2 * 256)  // MI355X: 256 CUs
     return f16 ? launch_halo_t<1, 256, 4>(d, zp, stream) : launch_halo_t<0, 256, 4>(d, zp, stream);
   // fewer than two 256-row workgroups per CU (NCSN++ level 1: 256): 128-row tiles of 4 waves, two of them per CU
@@ -1911,7 +1984,7 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
     const hipError_t e = igemm_halo3x3_launch(d, pl, stream);
     if (e != hipErrorNotSupported) return e;
   }
-  if (d.gnf_out) return hipErrorInvalidValue;  // (only the halo kernel finishes a GroupNorm: igemm_halo3x3_gnfin_ok)
+  if (d.gnf_out || d.sc_A) return hipErrorInvalidValue;  // (only the halo kernel takes these: igemm_halo3x3_gnfin_ok / _eligible)
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
   auto tiles = [&](int tm, int tn) { return (long)cdiv(d.M, tm) * cdiv(d.N, tn) * std::max(d.ksplit, 1); };
