@@ -841,7 +841,7 @@ struct dsn_ctx {
     if (profiling) {
       HIPCHK(hipEventCreate(&pr.a));
       HIPCHK(hipEventCreate(&pr.b));
-      pr.flops = 2.0 * (double)d.M * (double)d.N * (double)d.taps * (double)d.Cin;
+      pr.flops = 2.0 * (double)d.M * (double)d.N * ((double)d.taps * (double)d.Cin + (d.sc_A ? (double)d.sc_Cin : 0.0));
       pr.tag = cur_tag;
       HIPCHK(hipEventRecord(pr.a, st));
     }
