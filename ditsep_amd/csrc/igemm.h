@@ -137,6 +137,7 @@ hipError_t igemm_slab_epilogue_launch(const GemmDesc& d, int pl, const float* sl
 hipError_t igemm_halo3x3_launch(const GemmDesc& d, int pl, hipStream_t stream);
 // can `d` (with gnf_out set) run as a producer-finished GroupNorm conv: halo-kernel eligible and one resident round?
 bool igemm_halo3x3_gnfin_ok(const GemmDesc& d, int pl);
+bool igemm2_gnfin_ok(const GemmDesc& d, int pl);   // the same inside igemm2's 128 x 64 tile (128-pixel images, no hand-off)
 // will igemm2_launch run `d` on the halo kernel (the only one that takes sc_A)?
 bool igemm_halo3x3_eligible(const GemmDesc& d, int pl);
 // `pl` = DSN_PL(plane count, fp16 flag)

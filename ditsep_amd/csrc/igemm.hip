@@ -934,6 +934,85 @@ __global__ __launch_bounds__((TBM / 64) * (TBN / WTN) * 64, 1) void igemm2_kerne
     }
   }
   epilogue_gen<P, F16, NT, 4, 0, LEAN>(d, acc, m0 + wm * 64, d.M, n0 + wn * WTN, lane, z);
+  if constexpr (P == 1 && TBM == 128 && TBN == 64 && WTN == 32 && LEAN == 0) {
+    if (d.gnf_out) {
+      // ---- GroupNorm finished by this workgroup alone (GemmDesc::gnf_out with 128-pixel images: the tile IS the
+      // image, its 64 columns hold whole groups): the epilogue above stored nothing but the two slices' partials; they are
+      // combined exactly as gn_apply_kernel does and silu(GroupNorm(out)) goes to the next conv's operand plane from the
+      // accumulators.  No other workgroup is involved (igemm_halo3x3_kernel has the cross-workgroup form).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      float* const gm = reinterpret_cast<float*>(lds);
+      float* const gr = gm + 64;
+      const int HW = d.rows_per_b, b = m0 / HW;
+      const int C = d.N, nq_all = C >> 2;
+      const int G = min(C >> 2, 32), cpg = C / G, qpg = cpg >> 2;
+      const int S = HW >> 6;
+      int tpg = 1;
+      while (tpg < 64 && G * tpg * 2 <= 256) tpg *= 2;
+      const int ngt = min(TBN, C - n0) / cpg;
+      {
+        const int gl = tid / tpg, sub = tid - gl * tpg;
+        const bool live = gl < ngt;
+        const float* sp = d.gn_stats + ((long)b * S * nq_all + (long)(n0 / cpg + (live ? gl : 0)) * qpg) * 2;
+        const int items = S * qpg;
+        const float cnt = 256.f;
+        float wsum = 0.f;
+        if (live)
+          for (int it = sub; it < items; it += tpg) {
+            const int sl = it / qpg, q2 = it - sl * qpg;
+            wsum += cnt * __hip_atomic_load(sp + ((long)sl * nq_all + q2) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        for (int o = tpg >> 1; o >= 1; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+        const float ntot = (float)HW * (float)cpg;
+        const float mean = wsum / ntot;
+        float m2 = 0.f;
+        if (live)
+          for (int it = sub; it < items; it += tpg) {
+            const int sl = it / qpg, q2 = it - sl * qpg;
+            const float* pp = sp + ((long)sl * nq_all + q2) * 2;
+            const float px = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float py = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float dm = px - mean;
+            m2 += py + cnt * dm * dm;
+          }
+        for (int o = tpg >> 1; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        if (live && sub == 0) {
+          gm[gl] = mean;
+          gr[gl] = rsqrtf(m2 / ntot + d.gnf_eps);
+        }
+      }
+      __syncthreads();
+      const int nqc = (lane >> 4) * 4;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n = n0 + wn * WTN + tn * 16 + nqc;
+        if (n >= C) continue;
+        const int gl = (n - n0) / cpg;
+        const float mean = gm[gl], rstd = gr[gl];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(d.gnf_gamma + n);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(d.gnf_beta + n);
+        const f32x4 bias4 = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + (n % d.bias_mod)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+          if (m >= d.M) continue;
+          // the value the epilogue would have stored: (acc + bias) + per-item bias, scaled (same order of operations)
+          f32x4 v = acc[tn][tm] + bias4;
+          if (d.bbias) v += *reinterpret_cast<const f32x4*>(d.bbias + (long)b * d.bbias_stride + n);
+          op16x4 h;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float vk = v[k] * d.out_scale;
+            asm volatile("" : "+v"(vk));  // (rounded on its own, as the stored fp32 tensor would hold it)
+            float tt = (vk - mean) * rstd * ga[k] + be[k];
+            h[k] = to_op16(d.gnf_silu ? dsn_silu(tt) : tt, F16);
+          }
+          *reinterpret_cast<op16x4*>(d.gnf_out + (long)m * C + n) = h;
+        }
+      }
+    }
+  }
 }
 
 // ============================================================================
@@ -1817,6 +1896,9 @@ hipError_t igemm2_launch_cfg(const GemmDesc& din, int pl, int bm, int bn, int ns
   if (planes == P_ && bm == BM_ && bn == BN_ && nst == NS_ && bk == BK_)              \
     return f16 ? launch_cfg<P_, 1, BM_, BN_, NS_, BK_>(d, zp, stream)                 \
                : launch_cfg<P_, 0, BM_, BN_, NS_, BK_>(d, zp, stream);
+  if (d.sc_A || (d.gnf_out && !(planes == 1 && bm == 128 && bn == 64 && nst == 3 && bk == 64 && igemm2_gnfin_ok(d, pl) &&
+                                d.gnf_gamma && d.gnf_beta && !d.out_f32 && !d.out_planes)))
+    return hipErrorInvalidValue;
   if (planes == 1 && bm == 128 && bn == 64 && nst == 3 && bk == 64)   // 4 waves of 64 x 32 (NCSN++ level 2)
     return f16 ? launch_cfg<1, 1, 128, 64, 3, 64, 0, 32>(d, zp, stream) : launch_cfg<1, 0, 128, 64, 3, 64, 0, 32>(d, zp, stream);
   // split (2-plane) modes: 48 MFMAs per wave per 32-deep k-tile already amortise the barrier
@@ -1871,6 +1953,16 @@ static int halo_resident_blocks() {
       hipGetDeviceProperties(&prop, dsn_current_device()) != hipSuccess)
     return 0;
   return per_cu * prop.multiProcessorCount;
+}
+// GroupNorm finished inside igemm2's 128 x 64 tile (128-pixel images: one workgroup holds the image).  The caller
+// forces that tile (cfg_bm/bn/nst/bk = 128, 64, 3, 64).
+bool igemm2_gnfin_ok(const GemmDesc& d, int pl) {
+  if (getenv("DSN_NO_GN_FIN") != nullptr || PL_COUNT(pl) != 1 || !d.gn_stats || d.rows_per_b != 128 || d.M % 128 != 0 ||
+      d.N % 64 != 0 || d.N > 1024 || d.Cin % 64 != 0 || d.ksplit > 1 || d.resid || d.out_scale != 1.f || d.swiglu ||
+      d.rope_cos || d.qkv_D > 0)
+    return false;
+  const int G = std::min(d.N / 4, 32), cpg = d.N / G;
+  return cpg % 4 == 0 && 64 % cpg == 0;
 }
 bool igemm_halo3x3_eligible(const GemmDesc& d, int pl) {
   return getenv("DSN_NO_HALO") == nullptr && halo_variant(d, pl) != 0;
@@ -1984,7 +2076,7 @@ hipError_t igemm2_launch(const GemmDesc& d, int pl, hipStream_t stream) {
     const hipError_t e = igemm_halo3x3_launch(d, pl, stream);
     if (e != hipErrorNotSupported) return e;
   }
-  if (d.gnf_out || d.sc_A) return hipErrorInvalidValue;  // (only the halo kernel takes these: igemm_halo3x3_gnfin_ok / _eligible)
+  if (d.gnf_out || d.sc_A) return hipErrorInvalidValue;  // (the halo kernel, or the forced 128 x 64 tile above, take these)
   int bm = 128, bn = 128, nst = planes == 2 ? 2 : 3, bk = 32;
   const bool k64 = planes == 1 && d.Cin % 64 == 0;
   auto tiles = [&](int tm, int tn) { return (long)cdiv(d.M, tm) * cdiv(d.N, tn) * std::max(d.ksplit, 1); };
