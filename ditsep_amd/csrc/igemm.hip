@@ -1957,7 +1957,7 @@ static int halo_resident_blocks() {
 // GroupNorm finished inside igemm2's 128 x 64 tile (128-pixel images: one workgroup holds the image).  The caller
 // forces that tile (cfg_bm/bn/nst/bk = 128, 64, 3, 64).
 bool igemm2_gnfin_ok(const GemmDesc& d, int pl) {
-  if (getenv("DSN_NO_GN_FIN") != nullptr || PL_COUNT(pl) != 1 || !d.gn_stats || d.rows_per_b != 128 || d.M % 128 != 0 ||
+  if (getenv("DSN_NO_GN_FIN") != nullptr || getenv("DSN_NO_GN_FIN_L2") != nullptr || PL_COUNT(pl) != 1 || !d.gn_stats || d.rows_per_b != 128 || d.M % 128 != 0 ||
       d.N % 64 != 0 || d.N > 1024 || d.Cin % 64 != 0 || d.ksplit > 1 || d.resid || d.out_scale != 1.f || d.swiglu ||
       d.rope_cos || d.qkv_D > 0)
     return false;
